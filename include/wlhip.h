@@ -1,0 +1,165 @@
+/* wlhip.h — C ABI of libwlhip.so: the MI355X (gfx950) backend for WaterLily's time-step hot path.
+ *
+ * Boundary being replaced: the reference has no FFI — it selects a backend by Julia multiple dispatch
+ * on the array type (`Simulation(...; mem=ArrayType)`, /root/reference/src/WaterLily.jl:67-68,98;
+ * src/Flow.jl:133-146) and generates every kernel from `@loop` through KernelAbstractions
+ * (src/core.jl:125-156).  This header is what a Julia package extension binds with `ccall` for a new
+ * array type: every entry point cites the reference function it stands in for.
+ *
+ * Conventions
+ *  - Arrays are dense, column-major, x fastest, vector component slowest — byte-identical to the Julia
+ *    arrays (scalar (Ng...), vector (Ng...,D), tensor (Ng...,D,D)), so `pointer(a)` is passed with no copy.
+ *  - All pointers are DEVICE pointers unless named host_*.  Element type: Float32.
+ *  - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream)
+ *    unless it returns a host scalar, in which case it synchronises that stream.
+ *  - Return value: 0 = ok; >0 = hipError_t; <0 = library error (WL_E*).  wl_last_error_string() gives text.
+ *    No exception crosses this boundary.
+ *  - Aliasing pois.x≡flow.p, pois.L≡flow.μ₀, pois.z≡flow.σ (src/WaterLily.jl:97) is allowed everywhere.
+ */
+#ifndef WLHIP_H
+#define WLHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WL_EINVAL (-1)   /* bad argument (the reference's @assert failures map here) */
+#define WL_ENOGPU (-2)   /* no usable HIP device */
+#define WL_ELEVELS (-3)  /* "MultiLevelPoisson requires size=a2ⁿ, where n>2" (src/MultiLevelPoisson.jl:73-74) */
+#define WL_ECOMM (-4)    /* halo/collective failure */
+
+/* Grid descriptor of one (slab of a) Cartesian array with one ghost layer per side in x,y and
+ * `k0` ghost planes in z.  A single-GPU array is the case gk=0, gnz=nz, k0=1, k1=nz-1.
+ * For D==2: nz=1, k0=0, k1=1, gnz=1. */
+typedef struct wl_grid {
+  int32_t D;        /* 2 or 3 */
+  int32_t nx, ny, nz; /* allocated extents INCLUDING ghosts */
+  int32_t k0, k1;   /* local z planes [k0,k1) are the interior planes this rank owns */
+  int32_t gk;       /* global z index (0-based, ghosts included) of local plane 0 */
+  int32_t gnz;      /* global z extent including ghosts */
+} wl_grid;
+
+/* convective schemes λ(u,c,d): src/Flow.jl:4-6 */
+enum { WL_QUICK = 0, WL_VANLEER = 1, WL_CDS = 2 };
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+int wl_init(int device);                       /* hipSetDevice + capability check (gfx950)           */
+const char* wl_last_error_string(void);
+int wl_version(void);
+int wl_malloc(void** p, size_t bytes);          /* device allocation owned by the caller (Julia finalizer -> wl_free) */
+int wl_free(void* p);
+int wl_h2d(void* dst, const void* host_src, size_t bytes, void* stream);   /* `mem(::Array)` ctor, src/Flow.jl:139,143-144 */
+int wl_d2h(void* host_dst, const void* src, size_t bytes, void* stream);   /* `Array(a)`                      */
+int wl_d2d(void* dst, const void* src, size_t bytes, void* stream);        /* copy / `u⁰ .= u`, src/Flow.jl:157 */
+int wl_stream_sync(void* stream);
+wl_grid wl_grid_single(int D, const int32_t* dims_with_ghosts);            /* host helper: single-domain descriptor */
+
+/* ---- generic array ops the array type must support ------------------------------ */
+int wl_fill(float* a, float v, size_t n, void* stream);                    /* fill!, `r .= 0` src/Flow.jl:39, MultiLevelPoisson.jl:94 */
+int wl_scale(float* a, float s, size_t n, void* stream);                   /* `x .*= dt` src/Flow.jl:225             */
+int wl_div_scalar(float* a, float s, size_t n, void* stream);              /* `x ./= dt` src/Flow.jl:230             */
+int wl_sum(const float* a, size_t n, double* host_out, void* stream);      /* sum(a)     src/Poisson.jl:95            */
+int wl_sum_abs_max_abs(const float* a, size_t n, double* host_l1, float* host_linf, void* stream); /* L₁,L∞ src/Poisson.jl:190-191 */
+int wl_max(const float* a, size_t n, float* host_out, void* stream);       /* maximum(a) src/Flow.jl:236              */
+int wl_dot(const float* a, const float* b, size_t n, double* host_out, void* stream); /* a⋅b  src/Poisson.jl:156,189   */
+int wl_L2_inside(const float* a, const wl_grid* g, double* host_out, void* stream);   /* L₂(a) src/Poisson.jl:188; ext/WaterLilyAMDGPUExt.jl:18 */
+
+/* ---- boundary conditions: src/core.jl:200-243 ------------------------------------------------ */
+/* BC!(a,U::tuple,saveexit,perdir): all faces, all components, one launch (edge/corner values equal the
+ * reference's sequential (i,j) order).  perdir_mask bit (j-1) set = direction j periodic.            */
+int wl_bc_vec(float* a, const wl_grid* g, const float* host_U, int saveexit, unsigned perdir_mask, void* stream);
+int wl_bc_per_scalar(float* a, const wl_grid* g, unsigned perdir_mask, void* stream);   /* perBC!   src/core.jl:239-243 */
+int wl_exit_bc(float* u, const float* u0, const wl_grid* g, float dt, void* stream);    /* exitBC!  src/core.jl:226-233 */
+
+/* ---- Flow: src/Flow.jl ------------------------------------------------------------------------ */
+/* conv_diff!(r,u,Φ,λ;ν,perdir) :38-62 — gather form, one launch; Φ (=flow.σ) receives the same stale
+ * ghost-plane fluxes the reference leaves there. Φ may be NULL.                 */
+int wl_conv_diff(float* r, const float* u, float* Phi, const wl_grid* g, float nu, unsigned perdir_mask, int scheme, void* stream);
+/* BDIM!(a) :176-180 with the neighbouring scale_u! folded in: u = (u*pre + μddn(μ₁,f) + V + μ₀ f)*post,
+ * f = u⁰ + dt f − V on all cells.  mu1 may be NULL (== zeros, NoBody fast path), V may be NULL (== zeros). */
+int wl_bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1,
+            const wl_grid* g, float dt, float pre, float post, void* stream);
+int wl_scale_u(float* u, const wl_grid* g, float s, void* stream);                      /* scale_u! :211-214 */
+int wl_div(float* z, const float* u, const wl_grid* g, void* stream);                   /* @inside z = div(I,u) :225 */
+int wl_project(float* u, const float* L, const float* x, const wl_grid* g, void* stream); /* u[I,i] -= L[I,i]∂ᵢx :227-229 */
+/* CFL(a) :234-237 — writes σ=flux_out on the interior and returns min(Δt_max, 1/(max(σ over ALL cells)+5ν)) */
+int wl_cfl(const float* u, float* sigma, const wl_grid* g, float nu, float dt_max, float* host_dt, void* stream);
+
+/* ---- Poisson leaf operations: src/Poisson.jl --------------------------------------------------- */
+int wl_set_diag(float* D, float* iD, const float* L, const wl_grid* g, void* stream);   /* set_diag! :43-46 */
+int wl_mult(float* z, const float* L, const float* D, const float* x, const wl_grid* g, void* stream); /* mult! :63-69 (no perBC, z ghosts zeroed) */
+/* residual! :92-98 — r = iD==0 ? 0 : z−Ax; s=Σr/N; if |s|>2eps: r-=s.  No host sync.
+ * scratch: device workspace of wl_reduce_workspace_bytes() bytes.                                   */
+int wl_residual(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD,
+                const wl_grid* g, void* scratch, void* stream);
+int wl_increment(float* r, float* x, const float* eps, const float* L, const float* D, const wl_grid* g, float omega, void* stream); /* increment! :100-104 */
+int wl_jacobi(float* eps, float* r, float* x, const float* L, const float* D, const float* iD, const wl_grid* g, int it, float omega,
+              unsigned perdir_mask, void* stream);                                      /* Jacobi! :111-114 */
+int wl_gsrb(float* eps, float* r, float* x, const float* L, const float* D, const float* iD, const wl_grid* g, int it, float omega,
+            unsigned perdir_mask, void* stream);                                        /* GaussSeidelRB! :141-148 */
+int wl_norms(const float* r, const wl_grid* g, double* host_l1, float* host_linf, void* scratch, void* stream); /* L₁, L∞ :190-191 */
+size_t wl_reduce_workspace_bytes(void);
+
+/* ---- multigrid transfer: src/MultiLevelPoisson.jl ---------------------------------------------- */
+int wl_restrict(float* a_coarse, const wl_grid* gc, const float* b_fine, const wl_grid* gf, void* stream);    /* restrict! :49 */
+int wl_prolongate(float* a_fine, const wl_grid* gf, const float* b_coarse, const wl_grid* gc, void* stream);  /* prolongate! :50 */
+int wl_restrictL(float* a_coarse, const wl_grid* gc, const float* b_fine, const wl_grid* gf, unsigned perdir_mask, void* stream); /* restrictL! :42-48 */
+int wl_coarsen_dims(int D, const int32_t* fine, int32_t* coarse);                      /* coarsen_mask/divisible :29,52; returns #dirs coarsened */
+
+/* ---- MultiLevelPoisson handle: struct :61-77, update! :79-86, Vcycle! :88-101, solver! :108-128 -- */
+typedef struct wl_mg wl_mg;
+/* x, L, z are the caller's (aliased) level-1 arrays; coarse levels and r,ϵ,D,iD are owned by the handle. */
+int wl_mg_create(wl_mg** out, float* x, float* L, float* z, const wl_grid* g, unsigned perdir_mask, int maxlevels);
+int wl_mg_destroy(wl_mg* mg);
+int wl_mg_update(wl_mg* mg, void* stream);
+int wl_mg_nlevels(const wl_mg* mg);
+int wl_mg_level_grid(const wl_mg* mg, int level, wl_grid* out);
+/* name ∈ "L","D","iD","x","eps","r","z" — device pointer of that level's array (tests read pois.levels[k].D etc.) */
+float* wl_mg_level_field(const wl_mg* mg, int level, const char* name);
+int wl_mg_vcycle(wl_mg* mg, int level, float omega, void* stream);
+/* solver!(ml;tol,itmx): returns iterations in *host_n and the last L₁/L∞; appends to the n history. */
+int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, void* stream);
+int wl_mg_history(const wl_mg* mg, int16_t* host_out, int cap);                        /* pois.n :66 */
+/* per-iteration log of the last solve: what `@log` prints (:112,117): r∞, r₁, ω */
+int wl_mg_last_log(const wl_mg* mg, double* host_r1, double* host_rinf, double* host_omega, int cap);
+
+/* ---- Simulation/Flow composite (what bench.py times): src/Flow.jl:156-167, src/WaterLily.jl:128-139 */
+typedef struct wl_sim wl_sim;
+typedef struct wl_sim_desc {
+  int32_t D;
+  int32_t dims[3];          /* interior cells N (no ghosts) */
+  float uBC[3];             /* tuple boundary velocity */
+  float nu, dt0;
+  uint32_t perdir_mask;
+  int32_t exitBC;
+  int32_t scheme;           /* WL_QUICK ... */
+  int32_t has_body;         /* 0: NoBody fast path (μ₁≡0, V≡0 never read) */
+  /* caller-owned flow arrays (NULL => the handle allocates and owns them) */
+  float *u, *u0, *f, *p, *sigma, *V, *mu0, *mu1;
+} wl_sim_desc;
+int wl_sim_create(wl_sim** out, const wl_sim_desc* desc);
+int wl_sim_destroy(wl_sim* s);
+float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sigma","V","mu0","mu1" */
+wl_mg* wl_sim_pois(wl_sim* s);
+int wl_sim_grid(const wl_sim* s, wl_grid* out);
+int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀ BC, (src/Flow.jl:141-145) after the caller filled u */
+int wl_sim_update(wl_sim* s, void* stream);             /* update!(pois) after μ₀ changed (measure!, src/WaterLily.jl:148) */
+int wl_sim_mom_step(wl_sim* s, void* stream);           /* mom_step!(flow,pois): appends Δt */
+int wl_sim_dt(const wl_sim* s, float* host_out, int cap);      /* flow.Δt (host vector, src/Flow.jl:127) */
+double wl_sim_time(const wl_sim* s);                    /* time(flow) = sum(Δt[1:end-1]) :174 */
+/* sub-phases for parity tests: 0 u⁰.=u;scale_u!(0) 1 mom_predict! 2 mom_project!(1) 3 mom_correct! 4 mom_project!(.5) 5 push!(Δt,CFL) */
+int wl_sim_phase(wl_sim* s, int phase, void* stream);
+/* analytic initial conditions evaluated on device (apply!(u0,u), src/Flow.jl:81-83): kind 0 = uBC tuple,
+ * 1 = wall-bounded 3-D TGV κ=π/N, 2 = periodic TGV κ=2π/N */
+int wl_sim_apply_ic(wl_sim* s, int kind, void* stream);
+/* measure!(flow, sphere(c,R); ϵ): closed-form AutoBody sphere/circle (src/Body.jl:28-51, src/AutoBody.jl:29-37) */
+int wl_sim_measure_sphere(wl_sim* s, const float* host_center, float R, float eps, void* stream);
+/* pressure_force(sim) for that sphere (src/Metrics.jl:116-133): Float64 accumulation, does not touch flow.f */
+int wl_sim_pressure_force_sphere(wl_sim* s, const float* host_center, float R, double* host_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WLHIP_H */

@@ -1,0 +1,225 @@
+"""Solver- and step-level parity of the HIP path (through the C ABI) against the oracle, including the
+reference's own known-answer tests re-run on the GPU path (file:line given per test)."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def F(shape, fill=0.0):
+    return np.full(shape, fill, dtype=np.float32, order="F")
+
+
+@pytest.fixture(scope="module")
+def w():
+    import waterlily_jl_amd as w
+    w.core.device()
+    return w
+
+
+def poisson_setup_gpu(w, oracle, N):
+    """Poisson_setup(MultiLevelPoisson,N)   test/test_poisson.jl:1-12 on the HIP path"""
+    D = len(N)
+    c = F(N + (D,), 1.0)
+    cg = w.to_device(c)
+    w.BC_(cg, (0,) * D)
+    xg, zg = w.jl_zeros(N), w.jl_zeros(N)
+    pois = w.MultiLevelPoisson(xg, cg, zg)
+    soln = np.asfortranarray(np.broadcast_to((np.arange(N[0], dtype=np.float32) + 1).reshape((N[0],) + (1,) * (D - 1)), N).copy(order="F"))
+    I = (1,) * D
+    soln -= soln[I]
+    # z = mult!(pois, soln)
+    lvl0 = w.Poisson.__new__(w.Poisson)
+    import ctypes as C
+    g = w.core.sgrid(xg)
+    D0 = pois.levels[0]
+    lib = w.lib()
+    sd = w.to_device(soln)
+    w._lib.check(lib.wl_mult(w.core.ptr(zg), w.core.ptr(cg), lib.wl_mg_level_field(pois._h, 0, b"D"), w.core.ptr(sd), C.byref(g), w.core.stream()))
+    n = pois.solver_()
+    x = w.to_host(xg)
+    x -= x[I]
+    err = oracle.L2(x - soln) / oracle.L2(soln)
+    return err, pois, n
+
+
+# test/test_poisson.jl:54-60
+def test_multilevel_coarse_diagonal_and_update(w, oracle):
+    err, pois, _ = poisson_setup_gpu(w, oracle, (10, 10))
+    D3 = np.array([[0, 0, 0, 0], [0, -2, -2, 0], [0, -2, -2, 0], [0, 0, 0, 0]], dtype=np.float32)
+    assert np.array_equal(pois.levels[2].D, D3)
+    assert err < 1e-5
+    pois.L[4:6, :, 0] = 0
+    pois.update_()
+    assert np.array_equal(pois.levels[2].D, D3 / 2)
+
+
+# test/test_poisson.jl:42  (the @assert of src/MultiLevelPoisson.jl:73-74)
+def test_too_few_levels_raises(w, oracle):
+    with pytest.raises(AssertionError, match="MultiLevelPoisson requires size=a2ⁿ, where n>2"):
+        poisson_setup_gpu(w, oracle, (15 + 2, 3**4 + 2))
+
+
+# test/test_poisson.jl:62-70
+def test_multigrid_convergence(w, oracle):
+    err, pois, n = poisson_setup_gpu(w, oracle, (2**6 + 2, 2**6 + 2))
+    assert err < 1e-6 and n <= 4 and pois.n[-1] == n
+    assert pois.level_norms(0)[1] < 2e-3
+    err, pois, n = poisson_setup_gpu(w, oracle, (2**4 + 2,) * 3)
+    assert err < 1e-6 and n <= 3
+
+
+@pytest.mark.parametrize("N", [(18, 18), (34, 34, 34), (66, 18, 10), (130, 18)])
+def test_solver_matches_oracle_per_iteration(w, oracle, N):
+    """same random problem on both paths: identical level hierarchy, per-iteration L₁/L∞/ω log within
+    f32 reduction tolerance, solution within 1e-5."""
+    rng = np.random.default_rng(31)
+    D = len(N)
+    L = np.asfortranarray(rng.uniform(0.2, 1.0, size=N + (D,)).astype(np.float32))
+    oracle.BC(L, (0,) * D)
+    x0 = np.asfortranarray(rng.uniform(-1, 1, size=N).astype(np.float32))
+    sl = tuple(slice(1, -1) for _ in range(D))
+    z = F(N)
+    zz = rng.uniform(-1, 1, size=tuple(n - 2 for n in N)).astype(np.float32)
+    z[sl] = zz - zz.mean()
+    xo, Lo, zo = x0.copy(order="F"), L.copy(order="F"), z.copy(order="F")
+    po = oracle.MultiLevelPoisson(xo, Lo, zo)
+    xg, Lg, zg = w.to_device(x0), w.to_device(L), w.to_device(z)
+    pg = w.MultiLevelPoisson(xg, Lg, zg)
+    assert len(pg.levels) == po.nlevels
+    for l in range(po.nlevels):
+        assert pg.levels[l].dims == po.level_dims(l)
+        assert np.array_equal(pg.levels[l].L, po.field("L", l)), l
+        assert np.array_equal(pg.levels[l].D, po.field("D", l)), l
+        assert np.array_equal(pg.levels[l].iD, po.field("iD", l)), l
+    no, ng = po.solve(), pg.solver_()
+    r1o, rio, wo = po.log()
+    r1g, rig, wg = pg.log()
+    assert ng == no
+    assert np.allclose(r1g, r1o, rtol=2e-4) and np.allclose(rig, rio, rtol=2e-3, atol=1e-6) and np.array_equal(wg, wo)
+    assert np.allclose(w.to_host(xg), xo, rtol=0, atol=1e-5 * max(1.0, np.abs(xo).max()))
+
+
+def test_vcycle_matches_oracle_on_every_level(w, oracle):
+    rng = np.random.default_rng(37)
+    N = (34, 18, 18)
+    D = 3
+    L = np.asfortranarray(rng.uniform(0.2, 1.0, size=N + (D,)).astype(np.float32))
+    oracle.BC(L, (0,) * D)
+    x0 = F(N)
+    z = F(N)
+    r0 = F(N)
+    r0[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=(32, 16, 16)).astype(np.float32)
+    po = oracle.MultiLevelPoisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    xg, Lg, zg = w.to_device(x0), w.to_device(L), w.to_device(z)
+    pg = w.MultiLevelPoisson(xg, Lg, zg)
+    po.field("r", 0)[...] = r0
+    import ctypes as C
+    lib = w.lib()
+    w._lib.check(lib.wl_h2d(lib.wl_mg_level_field(pg._h, 0, b"r"), r0.ctypes.data_as(C.c_void_p), r0.nbytes, w.core.stream()))
+    po.Vcycle(0, 0.9); pg.Vcycle_(0, 0.9)
+    for l in range(po.nlevels):
+        for name in ("r", "x"):
+            assert np.array_equal(getattr(pg.levels[l], name), po.field(name, l)), (l, name)
+
+
+def tgv3d(N):
+    kap = math.pi / N
+    return lambda i, x: (-math.sin(kap * x[0]) * math.cos(kap * x[1]) * math.cos(kap * x[2]) if i == 1 else
+                         (math.cos(kap * x[0]) * math.sin(kap * x[1]) * math.cos(kap * x[2]) if i == 2 else 0.0))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_tgv_steps_match_oracle(w, oracle, fused):
+    """3-D wall-bounded TGV at 32³: fields after 1..3 mom_step! against the oracle.
+    Tolerance: 2e-5 absolute on u (|u|≤1) and 2e-4 on p — f32 reductions decide the mean shift of r and
+    nothing else differs; Δt and pois.n must agree exactly/within 1 ulp."""
+    N = 32
+    nu = N / 1600.0
+    so = oracle.Simulation((N, N, N), (0, 0, 0), N, U=1, nu=nu, u0=tgv3d(N), T=np.float32)
+    u_init = so.u.copy(order="F")
+    if fused:
+        sg = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=nu, u0=u_init)
+    else:
+        sg = w.Simulation((N, N, N), (0, 0, 0), N, U=1, nu=nu, u0=u_init)
+    for step in range(3):
+        so.step(remeasure=False)
+        if fused:
+            sg.mom_step_()
+            ug, pgp, dtg, ng = sg.field("u"), sg.field("p"), sg.dt, sg.pois_n
+        else:
+            sg.sim_step_(remeasure=False)
+            ug, pgp, dtg, ng = w.to_host(sg.flow.u), w.to_host(sg.flow.p), sg.flow.dt, sg.pois.n
+        assert ng == so.pois_n
+        assert np.allclose(np.array(dtg, dtype=np.float64), np.array(so.dt), rtol=1e-6)
+        assert np.abs(ug - so.u).max() < 2e-5, step
+        assert np.abs(pgp - so.p).max() < 2e-4, step
+
+
+def test_fused_phases_match_oracle(w, oracle):
+    N = 16
+    so = oracle.Simulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, u0=tgv3d(N), T=np.float32)
+    sg = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, u0=so.u.copy(order="F"))
+    for ph in range(6):
+        so.phase(ph); sg.phase_(ph)
+        tol = 0 if ph in (0, 1, 3) else 2e-5
+        for name in ("u", "f"):
+            d = np.abs(sg.field(name) - so.field(name)).max()
+            assert d <= tol, (ph, name, d)
+    assert np.allclose(sg.dt[-1], so.dt[-1], rtol=1e-6)
+
+
+def test_periodic_tgv_2d_runs_and_matches(w, oracle):
+    """periodic 2-D TGV as in test/helper.jl:4-15 but with the initial field as u0 and tuple BCs (all directions
+    periodic, so uBC is never evaluated; Re=1e8 makes dU/dt negligible): 64², tU/L = π/100."""
+    Lg = 64
+    kap = 2 * math.pi / Lg
+    nu = 1 / (kap * 1e8)
+    ic = lambda i, x: -math.sin(kap * x[0]) * math.cos(kap * x[1]) if i == 1 else math.cos(kap * x[0]) * math.sin(kap * x[1])
+    so = oracle.Simulation((Lg, Lg), (0, 0), Lg, U=1, nu=nu, u0=ic, perdir=(1, 2), T=np.float32)
+    sg = w.FusedSimulation((Lg, Lg), (0, 0), Lg, U=1, nu=nu, perdir=(1, 2), u0=so.u.copy(order="F"))
+    so.step_until(math.pi / 100, remeasure=False)
+    sg.sim_step_(math.pi / 100)
+    assert len(sg.dt) == len(so.dt) and sg.pois_n == so.pois_n
+    ug = sg.field("u")
+    assert np.abs(ug - so.u).max() < 2e-5
+    ue = np.zeros_like(ug)
+    t = sg.time()
+    for i in (1, 2):
+        for a in range(ug.shape[0]):
+            for b in range(ug.shape[1]):
+                ue[a, b, i - 1] = ic(i, oracle.loc(i, (a + 1, b + 1))) * math.exp(-2 * kap**2 * nu * t)
+    assert oracle.L2(ug[:, :, 0] - ue[:, :, 0]) < 1e-4 and oracle.L2(ug[:, :, 1] - ue[:, :, 1]) < 1e-4   # test/test_flow.jl:107-108
+
+
+# test/test_flow.jl:76-84 on the HIP path
+def test_impulsive_flow_in_box(w, oracle):
+    U = (2 / 3, -1 / 3)
+    a = w.Flow((16, 16), U)
+    b = w.MultiLevelPoisson(a.p, a.mu0, a.sigma)
+    w.mom_step_(a, b)
+    u = w.to_host(a.u)
+    assert oracle.L2(u[:, :, 0] - np.float32(U[0])) < 2e-5
+    assert oracle.L2(u[:, :, 1] - np.float32(U[1])) < 1e-5
+
+
+def test_sphere_measure_steps_and_force(w, oracle):
+    """configs[3] in miniature: sphere R=4 in 32³ (closed-form measure!, BDIM with μ₁, pressure_force)."""
+    N, R = 32, 4.0
+    c = (N / 2 - 1,) * 3
+    nu = 2 * R / 3700
+    so = oracle.Simulation((N, N, N), (1, 0, 0), 2 * R, U=1, nu=nu, body=("sphere", c, R), T=np.float32)
+    sg = w.FusedSimulation((N, N, N), (1, 0, 0), 2 * R, U=1, nu=nu, has_body=True)
+    sg.measure_sphere_(c, R, 1.0)
+    for name, tol in (("mu0", 2e-6), ("mu1", 2e-6), ("V", 0)):
+        assert np.abs(sg.field(name) - so.field(name)).max() <= tol, name
+    # identical coefficients from here on so that the step comparison is about the step
+    sg.set_field("mu0", so.field("mu0")); sg.set_field("mu1", so.field("mu1")); sg.update_()
+    for step in range(3):
+        so.step(remeasure=False); sg.mom_step_()
+        assert sg.pois_n == so.pois_n
+        assert np.abs(sg.field("u") - so.u).max() < 5e-5
+    fo, fg = so.pressure_force(), sg.pressure_force_sphere(c, R)
+    assert np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())

@@ -1,0 +1,115 @@
+"""ctypes binding of libwlhip.so (include/wlhip.h).  There is NO CPU fallback: if the library is
+missing or no MI355X is visible, every compute entry point raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwlhip.so")
+
+
+class wl_grid(C.Structure):
+    _fields_ = [("D", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32),
+                ("k0", C.c_int32), ("k1", C.c_int32), ("gk", C.c_int32), ("gnz", C.c_int32)]
+
+
+class wl_sim_desc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("dims", C.c_int32 * 3), ("uBC", C.c_float * 3), ("nu", C.c_float), ("dt0", C.c_float),
+                ("perdir_mask", C.c_uint32), ("exitBC", C.c_int32), ("scheme", C.c_int32), ("has_body", C.c_int32),
+                ("u", C.c_void_p), ("u0", C.c_void_p), ("f", C.c_void_p), ("p", C.c_void_p), ("sigma", C.c_void_p),
+                ("V", C.c_void_p), ("mu0", C.c_void_p), ("mu1", C.c_void_p)]
+
+
+P, G = C.c_void_p, C.POINTER(wl_grid)
+f32, f64, i32, u32, sz = C.c_float, C.c_double, C.c_int, C.c_uint, C.c_size_t
+# name -> (restype, argtypes); every symbol include/wlhip.h declares
+SIGNATURES = {
+    "wl_init": (i32, [i32]),
+    "wl_last_error_string": (C.c_char_p, []),
+    "wl_version": (i32, []),
+    "wl_malloc": (i32, [C.POINTER(P), sz]),
+    "wl_free": (i32, [P]),
+    "wl_h2d": (i32, [P, P, sz, P]),
+    "wl_d2h": (i32, [P, P, sz, P]),
+    "wl_d2d": (i32, [P, P, sz, P]),
+    "wl_stream_sync": (i32, [P]),
+    "wl_grid_single": (wl_grid, [i32, C.POINTER(C.c_int32)]),
+    "wl_fill": (i32, [P, f32, sz, P]),
+    "wl_scale": (i32, [P, f32, sz, P]),
+    "wl_div_scalar": (i32, [P, f32, sz, P]),
+    "wl_sum": (i32, [P, sz, C.POINTER(f64), P]),
+    "wl_sum_abs_max_abs": (i32, [P, sz, C.POINTER(f64), C.POINTER(f32), P]),
+    "wl_max": (i32, [P, sz, C.POINTER(f32), P]),
+    "wl_dot": (i32, [P, P, sz, C.POINTER(f64), P]),
+    "wl_L2_inside": (i32, [P, G, C.POINTER(f64), P]),
+    "wl_bc_vec": (i32, [P, G, C.POINTER(f32), i32, u32, P]),
+    "wl_bc_per_scalar": (i32, [P, G, u32, P]),
+    "wl_exit_bc": (i32, [P, P, G, f32, P]),
+    "wl_conv_diff": (i32, [P, P, P, G, f32, u32, i32, P]),
+    "wl_bdim": (i32, [P, P, P, P, P, P, G, f32, f32, f32, P]),
+    "wl_scale_u": (i32, [P, G, f32, P]),
+    "wl_div": (i32, [P, P, G, P]),
+    "wl_project": (i32, [P, P, P, G, P]),
+    "wl_cfl": (i32, [P, P, G, f32, f32, C.POINTER(f32), P]),
+    "wl_set_diag": (i32, [P, P, P, G, P]),
+    "wl_mult": (i32, [P, P, P, P, G, P]),
+    "wl_residual": (i32, [P, P, P, P, P, P, G, P, P]),
+    "wl_increment": (i32, [P, P, P, P, P, G, f32, P]),
+    "wl_jacobi": (i32, [P, P, P, P, P, P, G, i32, f32, u32, P]),
+    "wl_gsrb": (i32, [P, P, P, P, P, P, G, i32, f32, u32, P]),
+    "wl_norms": (i32, [P, G, C.POINTER(f64), C.POINTER(f32), P, P]),
+    "wl_reduce_workspace_bytes": (sz, []),
+    "wl_restrict": (i32, [P, G, P, G, P]),
+    "wl_prolongate": (i32, [P, G, P, G, P]),
+    "wl_restrictL": (i32, [P, G, P, G, u32, P]),
+    "wl_coarsen_dims": (i32, [i32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "wl_mg_create": (i32, [C.POINTER(P), P, P, P, G, u32, i32]),
+    "wl_mg_destroy": (i32, [P]),
+    "wl_mg_update": (i32, [P, P]),
+    "wl_mg_nlevels": (i32, [P]),
+    "wl_mg_level_grid": (i32, [P, i32, G]),
+    "wl_mg_level_field": (P, [P, i32, C.c_char_p]),
+    "wl_mg_vcycle": (i32, [P, i32, f32, P]),
+    "wl_mg_solve": (i32, [P, f64, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f32), P]),
+    "wl_mg_history": (i32, [P, C.POINTER(C.c_int16), i32]),
+    "wl_mg_last_log": (i32, [P, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), i32]),
+    "wl_sim_create": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc)]),
+    "wl_sim_destroy": (i32, [P]),
+    "wl_sim_field": (P, [P, C.c_char_p]),
+    "wl_sim_pois": (P, [P]),
+    "wl_sim_grid": (i32, [P, G]),
+    "wl_sim_init_flow": (i32, [P, P]),
+    "wl_sim_update": (i32, [P, P]),
+    "wl_sim_mom_step": (i32, [P, P]),
+    "wl_sim_dt": (i32, [P, C.POINTER(f32), i32]),
+    "wl_sim_time": (f64, [P]),
+    "wl_sim_phase": (i32, [P, i32, P]),
+    "wl_sim_apply_ic": (i32, [P, i32, P]),
+    "wl_sim_measure_sphere": (i32, [P, C.POINTER(f32), f32, f32, P]),
+    "wl_sim_pressure_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),
+}
+
+_lib = None
+
+
+class WlError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libwlhip.so (built by waterlily.jl_amd/csrc/Makefile).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WlError(f"{LIB_PATH} not found: build it with `make -C waterlily.jl_amd/csrc` (no CPU fallback exists)")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise WlError(f"libwlhip error {rc}: {lib().wl_last_error_string().decode(errors='replace')}")

@@ -1,0 +1,270 @@
+// C ABI of libwlhip.so (see include/wlhip.h): context, leaf wrappers and the MultiLevelPoisson handle.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "wl_common.hpp"
+#include "wl_mg.hpp"
+
+static thread_local std::string g_err;
+void wl_set_error(const std::string& s) { g_err = s; }
+
+WlCtx& wl_ctx() { static WlCtx c; return c; }
+int wl_ctx_ensure() {
+  WlCtx& c = wl_ctx();
+  if (c.inited) return 0;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { wl_set_error("libwlhip: no HIP device visible — the HIP path has no CPU fallback"); return WL_ENOGPU; }
+  WL_HIP(hipGetDevice(&c.device));
+  WL_HIP(hipMalloc(&c.red, wl_red_bytes()));
+  WL_HIP(hipHostMalloc((void**)&c.h_d, 8 * sizeof(double), hipHostMallocDefault));
+  WL_HIP(hipHostMalloc((void**)&c.h_f, 8 * sizeof(float), hipHostMallocDefault));
+  c.inited = true;
+  return 0;
+}
+
+// ================================================================================================
+// MultiLevelPoisson handle
+// ================================================================================================
+static inline bool divisible(int n) { return (n % 2 == 0) && n > 4; }   // src/MultiLevelPoisson.jl:52
+
+int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels) {
+  perdir = per;
+  WL_TRY(wl_ctx_ensure());
+  WL_HIP(hipMalloc(&red, wl_red_bytes()));
+  ws = wl_red_ws(red);
+  // level 1 aliases the caller's arrays; r,ϵ,D,iD owned                                 src/Poisson.jl:32-38
+  std::vector<wl_grid> grids; grids.push_back(g0);
+  while ((int)grids.size() <= maxlevels) {                                               // :70
+    const wl_grid& f = grids.back();
+    const bool cx = divisible(f.nx), cy = divisible(f.ny), cz = (f.D == 3) && divisible(f.gnz);
+    if (!(cx || cy || cz)) break;                                                        // divisible(l) :54
+    wl_grid c = f;
+    if (cx) c.nx = 1 + f.nx / 2;                                                         // restrictML :36
+    if (cy) c.ny = 1 + f.ny / 2;
+    if (cz) {
+      // z-slab: interior planes must pair up inside the rank (global interior start is odd in 0-based => local count even)
+      const int nloc = f.k1 - f.k0;
+      if (f.nz != f.gnz && (nloc % 2 != 0)) break;   // distributed level cannot be coarsened further locally (caller agglomerates)
+      c.gnz = 1 + f.gnz / 2;
+      const int nl = nloc / 2;
+      c.k0 = f.k0; c.k1 = c.k0 + nl; c.nz = nl + 2 * c.k0;
+      // global index of first interior plane: fine G = gk+k0 (odd, >=1) -> coarse (G+1)/2
+      c.gk = (f.gk + f.k0 + 1) / 2 - c.k0;
+      if (f.nz == f.gnz) { c.nz = c.gnz; c.k0 = 1; c.k1 = c.nz - 1; c.gk = 0; }
+    }
+    grids.push_back(c);
+  }
+  if (grids.size() <= 2) { wl_set_error("MultiLevelPoisson requires size=a2ⁿ, where n>2"); return WL_ELEVELS; }   // :73-74
+  // one slab allocation for everything the handle owns
+  size_t total = 0;
+  for (size_t l = 0; l < grids.size(); l++) { const size_t nc = (size_t)wl_ncell(grids[l]); total += (l == 0 ? 4 : 4 + 2 + (size_t)grids[l].D) * nc; }
+  WL_HIP(hipMalloc((void**)&slab, total * sizeof(float)));
+  WL_HIP(hipMemset(slab, 0, total * sizeof(float)));
+  float* p = slab;
+  lv.resize(grids.size());
+  for (size_t l = 0; l < grids.size(); l++) {
+    Level& v = lv[l]; v.g = grids[l]; v.x_ = gx(grids[l]);
+    const size_t nc = (size_t)wl_ncell(grids[l]);
+    v.r = p; p += nc; v.eps = p; p += nc; v.D = p; p += nc; v.iD = p; p += nc;
+    if (l == 0) { v.x = x; v.L = L; v.z = z; }
+    else { v.L = p; p += nc * (size_t)grids[l].D; v.x = p; p += nc; v.z = p; p += nc; }
+  }
+  hipStream_t s = 0;
+  for (size_t l = 1; l < lv.size(); l++) WL_TRY(wl::restrictL(lv[l].L, lv[l].x_, lv[l - 1].L, lv[l - 1].x_, perdir, s));    // restrictML :39
+  for (size_t l = 0; l < lv.size(); l++) WL_TRY(wl::set_diag(lv[l].D, lv[l].iD, lv[l].L, lv[l].x_, s));                  // Poisson ctor :36
+  WL_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+wl_mg::~wl_mg() { if (slab) (void)hipFree(slab); if (red) (void)hipFree(red); }
+
+int wl_mg::update(hipStream_t s) {                                                        // update! :79-86
+  WL_TRY(wl::set_diag(lv[0].D, lv[0].iD, lv[0].L, lv[0].x_, s));
+  for (size_t l = 1; l < lv.size(); l++) {
+    WL_TRY(wl::restrictL(lv[l].L, lv[l].x_, lv[l - 1].L, lv[l - 1].x_, perdir, s));
+    WL_TRY(wl::set_diag(lv[l].D, lv[l].iD, lv[l].L, lv[l].x_, s));
+  }
+  return 0;
+}
+// GaussSeidelRB!(p;it,ω)                                                                 src/Poisson.jl:141-148
+int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
+  Level& p = lv[(size_t)l];
+  WL_TRY(wl::gs_init(p.eps, p.r, p.iD, p.x_, s));
+  WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));
+  for (int k0 = 1; k0 <= it; k0++) WL_TRY(wl::gs_sweep(p.eps, p.r, p.L, p.iD, p.x_, k0, s));
+  WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));                                      // perBC!(ϵ) inside increment! :101
+  return wl::increment(p.r, p.x, p.eps, p.L, p.D, p.x_, w, s);
+}
+int wl_mg::vcycle(int l, float w, hipStream_t s) {                                        // Vcycle! :88-101
+  Level& fine = lv[(size_t)l]; Level& coarse = lv[(size_t)l + 1];
+  // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
+  WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
+  WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+  WL_TRY(wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, 1.f, s));
+  WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
+  WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
+  if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s));
+  WL_TRY(smooth(l + 1, 4, w, s));
+  if (perdir) {
+    WL_TRY(wl::prolongate(fine.eps, fine.x_, coarse.x, coarse.x_, s));
+    WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+    return wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, w, s);
+  }
+  return wl::prolong_increment(fine.r, fine.x, fine.eps, coarse.x, fine.L, fine.D, fine.x_, coarse.x_, w, true, s);
+}
+int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s) {   // solver! :108-128
+  Level& p = lv[0];
+  const double r1tol = (tol / 10.0) * (double)wl_ninside_global(p.g);                     // l1n_tol  src/Poisson.jl:194
+  const double rinftol = tol;
+  WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                        // residual!: perBC!(x) :93
+  WL_TRY(wl::residual(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));
+  WL_TRY(wl::norms_dev(p.r, p.x_, ws, 1, 0, s));                                          // r₁ -> res_d[1], r∞ -> res_f[0]
+  double hd[3]; float hf[2];
+  float w = 1.f;
+  // r₁ of the initial residual is only needed for the ω rule after the first V-cycle: fetch it lazily with the first iteration's norms
+  bool have_r1 = false; float r1 = 0.f, rinf = 0.f;
+  int np = 0;
+  log_r1.clear(); log_rinf.clear(); log_w.clear();
+  while (np < itmx) {
+    WL_TRY(vcycle(0, w, s));
+    WL_TRY(smooth(0, 4, w, s));
+    WL_TRY(wl::norms_dev(p.r, p.x_, ws, 2, 1, s));                                        // rnew -> res_d[2], r∞ -> res_f[1]
+    WL_TRY(wl::read_results(ws, hd, 3, hf, 2, s));
+    if (!have_r1) { r1 = (float)hd[1]; log_r1.push_back(hd[1]); log_rinf.push_back(hf[0]); log_w.push_back(1.0); have_r1 = true; }
+    const float rnew = (float)hd[2]; rinf = hf[1]; np++;
+    log_r1.push_back((double)rnew); log_rinf.push_back((double)rinf); log_w.push_back((double)w);
+    if (rnew >= r1) w = (float)std::fmax(0.2, 0.9 * (double)w);                           // :118-119
+    else if (rnew < r1) w = (float)std::fmin(1.0, 1.02 * (double)w);                      // :120-121
+    r1 = rnew;
+    if ((double)r1 < r1tol && (double)rinf < rinftol) break;
+  }
+  WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                        // :126
+  n.push_back((int16_t)np);
+  if (host_n) *host_n = np;
+  if (host_r1) *host_r1 = (double)r1;
+  if (host_rinf) *host_rinf = rinf;
+  return 0;
+}
+
+// ================================================================================================
+extern "C" {
+
+int wl_version(void) { return 100; }
+const char* wl_last_error_string(void) { return g_err.c_str(); }
+int wl_init(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { wl_set_error("libwlhip: no HIP device visible"); return WL_ENOGPU; }
+  WL_CHECK(device >= 0 && device < n, "device index out of range");
+  WL_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop; WL_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) { wl_set_error(std::string("libwlhip is built for gfx950 only, device is ") + prop.gcnArchName); return WL_ENOGPU; }
+  return wl_ctx_ensure();
+}
+int wl_malloc(void** p, size_t bytes) { WL_CHECK(p != nullptr, "null out pointer"); WL_HIP(hipMalloc(p, bytes)); return 0; }
+int wl_free(void* p) { WL_HIP(hipFree(p)); return 0; }
+int wl_h2d(void* dst, const void* src, size_t bytes, void* stream) { WL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, wl_stream(stream))); return 0; }
+int wl_d2h(void* dst, const void* src, size_t bytes, void* stream) { WL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, wl_stream(stream))); WL_HIP(hipStreamSynchronize(wl_stream(stream))); return 0; }
+int wl_d2d(void* dst, const void* src, size_t bytes, void* stream) { WL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, wl_stream(stream))); return 0; }
+int wl_stream_sync(void* stream) { WL_HIP(hipStreamSynchronize(wl_stream(stream))); return 0; }
+wl_grid wl_grid_single(int D, const int32_t* d) {
+  wl_grid g; g.D = D; g.nx = d[0]; g.ny = d[1];
+  if (D == 3) { g.nz = d[2]; g.k0 = 1; g.k1 = d[2] - 1; g.gk = 0; g.gnz = d[2]; }
+  else { g.nz = 1; g.k0 = 0; g.k1 = 1; g.gk = 0; g.gnz = 1; }
+  return g;
+}
+size_t wl_reduce_workspace_bytes(void) { return wl_red_bytes(); }
+
+#define GRID_ARG(g) WL_CHECK(wl_grid_ok(g), "bad wl_grid"); const GridX G = gx(*g)
+#define DEFAULT_WS() WL_TRY(wl_ctx_ensure()); const RedWs ws = wl_red_ws(wl_ctx().red)
+
+int wl_fill(float* a, float v, size_t n, void* st) { return wl::fill(a, v, n, wl_stream(st)); }
+int wl_scale(float* a, float s, size_t n, void* st) { return wl::scale(a, s, n, wl_stream(st)); }
+int wl_div_scalar(float* a, float s, size_t n, void* st) { return wl::div_scalar(a, s, n, wl_stream(st)); }
+int wl_sum(const float* a, size_t n, double* out, void* st) { DEFAULT_WS(); WL_TRY(wl::sum_dev(a, n, ws, 0, wl_stream(st))); return wl::read_results(ws, out, 1, nullptr, 0, wl_stream(st)); }
+int wl_sum_abs_max_abs(const float* a, size_t n, double* l1, float* linf, void* st) { DEFAULT_WS(); WL_TRY(wl::l1_linf_dev(a, n, ws, 0, 0, wl_stream(st))); return wl::read_results(ws, l1, 1, linf, 1, wl_stream(st)); }
+int wl_max(const float* a, size_t n, float* out, void* st) { DEFAULT_WS(); WL_TRY(wl::max_dev(a, n, ws, 0, wl_stream(st))); return wl::read_results(ws, nullptr, 0, out, 1, wl_stream(st)); }
+int wl_dot(const float* a, const float* b, size_t n, double* out, void* st) { DEFAULT_WS(); WL_TRY(wl::dot_dev(a, b, n, ws, 0, wl_stream(st))); return wl::read_results(ws, out, 1, nullptr, 0, wl_stream(st)); }
+
+int wl_bc_vec(float* a, const wl_grid* g, const float* U, int saveexit, unsigned per, void* st) { GRID_ARG(g); return wl::bc_vec(a, G, U, saveexit, per, wl_stream(st)); }
+int wl_bc_per_scalar(float* a, const wl_grid* g, unsigned per, void* st) { GRID_ARG(g); return wl::bc_per_scalar(a, G, per, wl_stream(st)); }
+int wl_conv_diff(float* r, const float* u, float* Phi, const wl_grid* g, float nu, unsigned per, int scheme, void* st) { GRID_ARG(g); return wl::conv_diff(r, u, Phi, G, nu, per, scheme, wl_stream(st)); }
+int wl_bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const wl_grid* g, float dt, float pre, float post, void* st) {
+  GRID_ARG(g); return wl::bdim(u, u0, f, V, mu0, mu1, G, dt, pre, post, wl_stream(st));
+}
+int wl_scale_u(float* u, const wl_grid* g, float s, void* st) { GRID_ARG(g); return wl::scale_u(u, G, s, wl_stream(st)); }
+int wl_div(float* z, const float* u, const wl_grid* g, void* st) { GRID_ARG(g); return wl::div(z, u, G, wl_stream(st)); }
+int wl_project(float* u, const float* L, const float* x, const wl_grid* g, void* st) { GRID_ARG(g); return wl::project(u, L, x, G, wl_stream(st)); }
+int wl_cfl(const float* u, float* sigma, const wl_grid* g, float nu, float dt_max, float* host_dt, void* st) {
+  GRID_ARG(g); DEFAULT_WS();
+  WL_TRY(wl::cfl_dev(u, sigma, G, ws, 0, wl_stream(st)));
+  float mx; WL_TRY(wl::read_results(ws, nullptr, 0, &mx, 1, wl_stream(st)));
+  *host_dt = std::fmin(dt_max, 1.0f / (mx + 5 * nu));                                    // src/Flow.jl:236
+  return 0;
+}
+int wl_set_diag(float* D, float* iD, const float* L, const wl_grid* g, void* st) { GRID_ARG(g); return wl::set_diag(D, iD, L, G, wl_stream(st)); }
+int wl_mult(float* z, const float* L, const float* D, const float* x, const wl_grid* g, void* st) { GRID_ARG(g); return wl::mult(z, L, D, x, G, wl_stream(st)); }
+int wl_residual(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const wl_grid* g, void* scratch, void* st) {
+  GRID_ARG(g); WL_TRY(wl_ctx_ensure());
+  const RedWs ws = wl_red_ws(scratch ? scratch : wl_ctx().red);
+  return wl::residual(r, x, z, L, D, iD, G, ws, wl_stream(st));
+}
+int wl_increment(float* r, float* x, const float* eps, const float* L, const float* D, const wl_grid* g, float w, void* st) { GRID_ARG(g); return wl::increment(r, x, eps, L, D, G, w, wl_stream(st)); }
+int wl_jacobi(float* eps, float* r, float* x, const float* L, const float* D, const float* iD, const wl_grid* g, int it, float w, unsigned per, void* st) {
+  GRID_ARG(g); hipStream_t s = wl_stream(st);
+  for (int k = 0; k < (it <= 0 ? 1 : it); k++) {
+    WL_TRY(wl::gs_init(eps, r, iD, G, s));
+    WL_TRY(wl::bc_per_scalar(eps, G, per, s));       // perBC!(ϵ) inside increment!  src/Poisson.jl:101
+    WL_TRY(wl::increment(r, x, eps, L, D, G, w, s));
+  }
+  return 0;
+}
+int wl_gsrb(float* eps, float* r, float* x, const float* L, const float* D, const float* iD, const wl_grid* g, int it, float w, unsigned per, void* st) {
+  GRID_ARG(g); hipStream_t s = wl_stream(st);
+  WL_TRY(wl::gs_init(eps, r, iD, G, s));
+  WL_TRY(wl::bc_per_scalar(eps, G, per, s));
+  for (int k0 = 1; k0 <= it; k0++) WL_TRY(wl::gs_sweep(eps, r, L, iD, G, k0, s));
+  WL_TRY(wl::bc_per_scalar(eps, G, per, s));
+  return wl::increment(r, x, eps, L, D, G, w, s);
+}
+int wl_norms(const float* r, const wl_grid* g, double* l1, float* linf, void* scratch, void* st) {
+  GRID_ARG(g); WL_TRY(wl_ctx_ensure());
+  const RedWs ws = wl_red_ws(scratch ? scratch : wl_ctx().red);
+  WL_TRY(wl::norms_dev(r, G, ws, 0, 0, wl_stream(st)));
+  return wl::read_results(ws, l1, 1, linf, 1, wl_stream(st));
+}
+int wl_restrict(float* a, const wl_grid* gc, const float* b, const wl_grid* gf, void* st) { WL_CHECK(wl_grid_ok(gc) && wl_grid_ok(gf), "bad wl_grid"); return wl::restrict_(a, gx(*gc), b, gx(*gf), wl_stream(st)); }
+int wl_prolongate(float* a, const wl_grid* gf, const float* b, const wl_grid* gc, void* st) { WL_CHECK(wl_grid_ok(gc) && wl_grid_ok(gf), "bad wl_grid"); return wl::prolongate(a, gx(*gf), b, gx(*gc), wl_stream(st)); }
+int wl_restrictL(float* a, const wl_grid* gc, const float* b, const wl_grid* gf, unsigned per, void* st) { WL_CHECK(wl_grid_ok(gc) && wl_grid_ok(gf), "bad wl_grid"); return wl::restrictL(a, gx(*gc), b, gx(*gf), per, wl_stream(st)); }
+int wl_coarsen_dims(int D, const int32_t* fine, int32_t* coarse) {
+  int c = 0;
+  for (int d = 0; d < D; d++) { if (divisible(fine[d])) { coarse[d] = 1 + fine[d] / 2; c++; } else coarse[d] = fine[d]; }
+  return c;
+}
+
+int wl_mg_create(wl_mg** out, float* x, float* L, float* z, const wl_grid* g, unsigned per, int maxlevels) {
+  WL_CHECK(out && x && L && z, "null pointer"); WL_CHECK(wl_grid_ok(g), "bad wl_grid");
+  wl_mg* mg = new wl_mg();
+  int rc = mg->build(x, L, z, *g, per, maxlevels <= 0 ? 10 : maxlevels);
+  if (rc != 0) { delete mg; *out = nullptr; return rc; }
+  *out = mg; return 0;
+}
+int wl_mg_destroy(wl_mg* mg) { delete mg; return 0; }
+int wl_mg_update(wl_mg* mg, void* st) { return mg->update(wl_stream(st)); }
+int wl_mg_nlevels(const wl_mg* mg) { return (int)mg->lv.size(); }
+int wl_mg_level_grid(const wl_mg* mg, int l, wl_grid* out) { WL_CHECK(l >= 0 && l < (int)mg->lv.size(), "level out of range"); *out = mg->lv[(size_t)l].g; return 0; }
+float* wl_mg_level_field(const wl_mg* mg, int l, const char* name) {
+  if (l < 0 || l >= (int)mg->lv.size()) return nullptr;
+  const wl_mg::Level& v = mg->lv[(size_t)l]; const std::string s(name);
+  if (s == "L") return v.L; if (s == "D") return v.D; if (s == "iD") return v.iD; if (s == "x") return v.x;
+  if (s == "eps") return v.eps; if (s == "r") return v.r; if (s == "z") return v.z;
+  return nullptr;
+}
+int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st)); }
+int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
+int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }
+int wl_mg_last_log(const wl_mg* mg, double* r1, double* rinf, double* w, int cap) {
+  const int n = (int)mg->log_r1.size();
+  for (int k = 0; k < n && k < cap; k++) { r1[k] = mg->log_r1[(size_t)k]; rinf[k] = mg->log_rinf[(size_t)k]; w[k] = mg->log_w[(size_t)k]; }
+  return n;
+}
+}  // extern "C"

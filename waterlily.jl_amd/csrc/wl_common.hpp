@@ -1,0 +1,159 @@
+// Shared device/host helpers for libwlhip (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/wlhip.h"
+
+#define WL_WAVE 64
+#define WL_BLOCK 256
+
+// ---- error plumbing ---------------------------------------------------------------------------
+void wl_set_error(const std::string& s);
+#define WL_HIP(call)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (call);                                                              \
+    if (e__ != hipSuccess) {                                                              \
+      wl_set_error(std::string(#call) + ": " + hipGetErrorString(e__));                   \
+      return (int)e__;                                                                    \
+    }                                                                                     \
+  } while (0)
+#define WL_CHECK(cond, msg)                                                               \
+  do {                                                                                    \
+    if (!(cond)) { wl_set_error(std::string(msg) + " [" #cond "]"); return WL_EINVAL; }   \
+  } while (0)
+#define WL_TRY(call)                 \
+  do {                               \
+    int r__ = (call);                \
+    if (r__ != 0) return r__;        \
+  } while (0)
+#define WL_LAUNCH_CHECK() WL_HIP(hipGetLastError())
+
+static inline hipStream_t wl_stream(void* s) { return (hipStream_t)s; }
+
+// ---- grid helpers (host + device) -------------------------------------------------------------
+struct GridX {  // wl_grid + precomputed strides, passed by value to kernels
+  int D, nx, ny, nz, k0, k1, gk, gnz;
+  long sy, sz, cs;  // row, plane and component strides (elements)
+};
+static inline GridX gx(const wl_grid& g) {
+  GridX x;
+  x.D = g.D; x.nx = g.nx; x.ny = g.ny; x.nz = g.nz; x.k0 = g.k0; x.k1 = g.k1; x.gk = g.gk; x.gnz = g.gnz;
+  x.sy = g.nx; x.sz = (long)g.nx * g.ny; x.cs = x.sz * g.nz;
+  return x;
+}
+static inline int wl_grid_ok(const wl_grid* g) {
+  if (!g) return 0;
+  if (g->D == 2) return g->nx >= 3 && g->ny >= 3 && g->nz == 1 && g->k0 == 0 && g->k1 == 1;
+  if (g->D == 3) return g->nx >= 3 && g->ny >= 3 && g->nz >= 3 && g->k0 >= 1 && g->k1 > g->k0 && g->k1 <= g->nz - 1 && g->gnz >= g->nz - 2 * (g->k0 - 1);
+  return 0;
+}
+static inline long wl_ncell(const wl_grid& g) { return (long)g.nx * g.ny * g.nz; }
+// number of interior cells owned by this rank
+static inline long wl_ninside_local(const wl_grid& g) { return (long)(g.nx - 2) * (g.ny - 2) * (g.D == 3 ? (g.k1 - g.k0) : 1); }
+static inline long wl_ninside_global(const wl_grid& g) { return (long)(g.nx - 2) * (g.ny - 2) * (g.D == 3 ? (g.gnz - 2) : 1); }
+
+// launch geometry: linear over an x-y plane (perfectly coalesced, ghosts masked), one z plane per blockIdx.y
+static inline dim3 wl_plane_grid(const GridX& g, int nplanes) { return dim3((unsigned)((g.sz + WL_BLOCK - 1) / WL_BLOCK), (unsigned)nplanes, 1); }
+
+#ifdef __HIPCC__
+// ---- wave / block reductions (wave64 shuffles, then LDS across the 4 waves of a 256-thread block) ----
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  return v;
+}
+// result valid in thread 0
+__device__ __forceinline__ double block_sum(double v) {
+  __shared__ double sh[WL_BLOCK / WL_WAVE];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { v = sh[0]; for (int i = 1; i < WL_BLOCK / WL_WAVE; i++) v += sh[i]; }
+  return v;
+}
+__device__ __forceinline__ float block_max(float v) {
+  __shared__ float shm[WL_BLOCK / WL_WAVE];
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) shm[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) { v = shm[0]; for (int i = 1; i < WL_BLOCK / WL_WAVE; i++) v = fmaxf(v, shm[i]); }
+  return v;
+}
+#endif
+
+// ---- reduction workspace layout (device) --------------------------------------------------------
+// [0 .. WL_MAXPART)              double partial sums  A
+// [WL_MAXPART .. 2*WL_MAXPART)   double partial sums  B
+// then WL_MAXPART floats         partial max
+// then 8 doubles + 8 floats      results  (res_d[0..7], res_f[0..7])
+#define WL_MAXPART 65536
+struct RedWs {
+  double* pa; double* pb; float* pm; double* res_d; float* res_f;
+};
+static inline size_t wl_red_bytes() { return (size_t)WL_MAXPART * (8 + 8 + 4) + 8 * 8 + 8 * 4 + 64; }
+static inline RedWs wl_red_ws(void* base) {
+  RedWs w; char* b = (char*)base;
+  w.pa = (double*)b; w.pb = (double*)(b + (size_t)WL_MAXPART * 8); w.pm = (float*)(b + (size_t)WL_MAXPART * 16);
+  w.res_d = (double*)(b + (size_t)WL_MAXPART * 20); w.res_f = (float*)(b + (size_t)WL_MAXPART * 20 + 64);
+  return w;
+}
+
+// process-wide context: pinned host scalars + a default reduction workspace
+struct WlCtx {
+  bool inited = false;
+  int device = 0;
+  void* red = nullptr;          // device reduction workspace
+  double* h_d = nullptr;        // pinned host: 8 doubles
+  float* h_f = nullptr;         // pinned host: 8 floats
+};
+WlCtx& wl_ctx();
+int wl_ctx_ensure();
+
+// ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
+namespace wl {
+int fill(float* a, float v, size_t n, hipStream_t s);
+int scale(float* a, float s_, size_t n, hipStream_t s);
+int div_scalar(float* a, float s_, size_t n, hipStream_t s);
+// reductions leave results in ws.res_d / ws.res_f on device; *_host variants copy to host & sync
+int sum_dev(const float* a, size_t n, const RedWs& ws, int slot, hipStream_t s);
+int l1_linf_dev(const float* a, size_t n, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
+int max_dev(const float* a, size_t n, const RedWs& ws, int slot_f, hipStream_t s);
+int dot_dev(const float* a, const float* b, size_t n, const RedWs& ws, int slot, hipStream_t s);
+int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s);
+
+int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per, hipStream_t s);
+int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
+int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
+int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s);
+int scale_u(float* u, const GridX& g, float sc, hipStream_t s);
+int div(float* z, const float* u, const GridX& g, hipStream_t s);
+int div_scale(float* z, float* x, const float* u, const GridX& g, float dt, hipStream_t s);   // z=div(u); x*=dt  (fused, src/Flow.jl:225)
+int project(float* u, const float* L, const float* x, const GridX& g, hipStream_t s);
+int cfl_dev(const float* u, float* sigma, const GridX& g, const RedWs& ws, int slot_f, hipStream_t s);
+
+int set_diag(float* D, float* iD, const float* L, const GridX& g, hipStream_t s);
+int mult(float* z, const float* L, const float* D, const float* x, const GridX& g, hipStream_t s);
+int residual(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s);
+// computes L₁/L∞ of r into ws.res_d[slot_d], ws.res_f[slot_f] (device) — ghosts of r are zero by construction
+int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
+int increment(float* r, float* x, const float* eps, const float* L, const float* D, const GridX& g, float w, hipStream_t s);
+int jacobi(float* eps, float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, bool write_eps, hipStream_t s);
+int gs_init(float* eps, const float* r, const float* iD, const GridX& g, hipStream_t s);
+int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const GridX& g, int k0, hipStream_t s);
+int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s);
+int prolongate(float* a, const GridX& gf, const float* b, const GridX& gc, hipStream_t s);
+int prolong_increment(float* r, float* x, float* eps, const float* xc, const float* L, const float* D, const GridX& gf, const GridX& gc, float w, bool write_eps, hipStream_t s);
+int restrictL(float* a, const GridX& gc, const float* b, const GridX& gf, unsigned per, hipStream_t s);
+}  // namespace wl

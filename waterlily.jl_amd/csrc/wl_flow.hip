@@ -1,0 +1,482 @@
+// Flow-side kernels for gfx950: conv_diff! (gather form), BDIM!, BC!, div, projection, CFL and the
+// generic array ops.  Reference semantics: /root/reference/src/Flow.jl, src/core.jl (file:line per kernel).
+// Arithmetic order follows the reference statement by statement (-ffp-contract=off).
+#include "wl_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ bool cell_ij(const GridX& g, long m, int& i, int& j) {
+  if (m >= g.sz) return false;
+  j = (int)(m / g.nx);
+  i = (int)(m - (long)j * g.nx);
+  return true;
+}
+__device__ __forceinline__ bool interior_ij(const GridX& g, int i, int j) { return i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2; }
+
+// ---- generic ------------------------------------------------------------------------------------
+__global__ void k_fill(float* __restrict__ a, float v, size_t n) {
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) a[q] = v;
+}
+__global__ void k_scale(float* __restrict__ a, float s, size_t n) {
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) a[q] = a[q] * s;
+}
+__global__ void k_divs(float* __restrict__ a, float s, size_t n) {
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) a[q] = a[q] / s;
+}
+__global__ void k_red_sum(const float* __restrict__ a, size_t n, double* __restrict__ part) {
+  double acc = 0.0;
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) acc += (double)a[q];
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ void k_red_l1_linf(const float* __restrict__ a, size_t n, double* __restrict__ part, float* __restrict__ pmax) {
+  double acc = 0.0; float mx = 0.f;
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) { const float v = fabsf(a[q]); acc += (double)v; mx = fmaxf(mx, v); }
+  acc = block_sum(acc); mx = block_max(mx);
+  if (threadIdx.x == 0) { part[blockIdx.x] = acc; pmax[blockIdx.x] = mx; }
+}
+__global__ void k_red_max(const float* __restrict__ a, size_t n, float* __restrict__ pmax) {
+  float mx = -INFINITY;
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) mx = fmaxf(mx, a[q]);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
+}
+__global__ void k_red_dot(const float* __restrict__ a, const float* __restrict__ b, size_t n, double* __restrict__ part) {
+  double acc = 0.0;
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) acc += (double)a[q] * (double)b[q];
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ void k_fin_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
+  double a = 0.0; for (int q = threadIdx.x; q < n; q += WL_BLOCK) a += part[q];
+  a = block_sum(a); if (threadIdx.x == 0) *out = a;
+}
+__global__ void k_fin_sum_max(const double* __restrict__ part, const float* __restrict__ pmax, int n, double* __restrict__ os, float* __restrict__ om) {
+  double a = 0.0; float mx = -INFINITY;
+  for (int q = threadIdx.x; q < n; q += WL_BLOCK) { a += part[q]; mx = fmaxf(mx, pmax[q]); }
+  a = block_sum(a); mx = block_max(mx);
+  if (threadIdx.x == 0) { *os = a; *om = mx; }
+}
+__global__ void k_fin_max(const float* __restrict__ pmax, int n, float* __restrict__ om) {
+  float mx = -INFINITY; for (int q = threadIdx.x; q < n; q += WL_BLOCK) mx = fmaxf(mx, pmax[q]);
+  mx = block_max(mx); if (threadIdx.x == 0) *om = mx;
+}
+
+// ---- convective schemes   src/Flow.jl:4-6,27-36 --------------------------------------------------
+__device__ __forceinline__ float median3(float a, float b, float c) {
+  if (a > b) { if (b >= c) return b; if (a > c) return c; }
+  else       { if (b <= c) return b; if (a < c) return c; }
+  return a;
+}
+template <int SCH> __device__ __forceinline__ float lam(float u, float c, float d) {
+  if (SCH == WL_QUICK) return median3((5 * c + 2 * d - u) / 6, c, median3(10 * c - 9 * u, c, d));
+  if (SCH == WL_VANLEER) return (c <= fminf(u, d) || c >= fmaxf(u, d)) ? c : c + (d - c) * (c - u) / (d - u);
+  return (c + d) / 2;
+}
+
+// flux Φ_ab at the lower b-face of the cell at offset o (component a advected, direction b).
+//  pb   : Julia index of that cell along b (2..Ng_b),  nb = Ng_b,  sb = stride along b, sa = stride along a
+//  variant by position: pb==2 lower boundary (ϕuL / periodic ϕuP), 3..nb-1 inner (ϕu), pb==nb upper (ϕuR / periodic reuse of index 2)
+//  returns the value V such that the reference does  r[I] += V  for the cell on the UPPER side of the face
+//  (lower/inner: V=Φ) — for the upper-boundary face the caller applies r[I-δ] += (-ϕuR + ν∂) itself.
+template <int SCH>
+__device__ __forceinline__ float flux_inner(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu) {
+  const float U = (ub[o] + ub[o - sa]) / 2;                                              // ϕ(i,CI(I,j),u)   src/Flow.jl:3,47
+  const float conv = U > 0 ? U * lam<SCH>(f[o - 2 * sb], f[o - sb], f[o]) : U * lam<SCH>(f[o + sb], f[o], f[o - sb]);   // ϕu :8
+  return conv - nu * (f[o] - f[o - sb]);
+}
+template <int SCH>
+__device__ __forceinline__ float flux_lowerL(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu) {
+  const float U = (ub[o] + ub[o - sa]) / 2;
+  const float conv = U > 0 ? U * ((f[o] + f[o - sb]) / 2) : U * lam<SCH>(f[o + sb], f[o], f[o - sb]);                   // ϕuL :10
+  return conv - nu * (f[o] - f[o - sb]);
+}
+template <int SCH>
+__device__ __forceinline__ float flux_lowerP(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu, long op) {
+  const float U = (ub[o] + ub[o - sa]) / 2;
+  const float conv = U > 0 ? U * lam<SCH>(f[op], f[o - sb], f[o]) : U * lam<SCH>(f[o + sb], f[o], f[o - sb]);           // ϕuP :9
+  return conv - nu * (f[o] - f[o - sb]);
+}
+template <int SCH>
+__device__ __forceinline__ float flux_upperR(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu) {
+  const float U = (ub[o] + ub[o - sa]) / 2;
+  const float conv = U < 0 ? U * ((f[o] + f[o - sb]) / 2) : U * lam<SCH>(f[o - 2 * sb], f[o - sb], f[o]);               // ϕuR :11
+  return -conv + nu * (f[o] - f[o - sb]);                                                 // upperBoundary! :57
+}
+
+// conv_diff!(r,u,Φ,λ;ν,perdir) in gather form   src/Flow.jl:38-62, ranges src/core.jl:55-57,188-190
+// One thread per cell of the WHOLE array (r .= 0 included).  For cell I (Julia indices) and component a:
+//   r[I,a] = Σ_b [ +Φ_ab(I) − Φ_ab(I+δ_b) ]  taken in the reference's (j inner) order, direction b
+//   contributing iff I_b ∈ 2..Ng_b−1 and every other I_c ∈ 2..Ng_c (upper ghost INCLUDED, as inside_u does).
+template <int D, int SCH>
+__global__ void k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float* __restrict__ Phi, float nu, unsigned per, int kfirst) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = (D == 3) ? kfirst + (int)blockIdx.y : 0;
+  const long o = m + (long)k * g.sz;
+  const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2};    // Julia (global) indices
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
+  const long st[3] = {1, g.sy, g.sz};
+  bool all_ge2 = true;
+  for (int c = 0; c < D; c++) all_ge2 = all_ge2 && (I[c] >= 2);
+  for (int a = 0; a < D; a++) {
+    const float* __restrict__ f = u + (long)a * g.cs;
+    float acc = 0.f;
+    if (all_ge2) {
+      for (int b = 0; b < D; b++) {
+        if (I[b] > N[b] - 1) continue;
+        const float* __restrict__ ub = u + (long)b * g.cs;
+        const long sb = st[b], sa = st[a];
+        const bool pb = (per >> b) & 1u;
+        // + flux at my own lower face
+        if (I[b] == 2) acc += pb ? flux_lowerP<SCH>(f, ub, o, sb, sa, nu, o + (long)(N[b] - 2 - I[b]) * sb) : flux_lowerL<SCH>(f, ub, o, sb, sa, nu);
+        else acc += flux_inner<SCH>(f, ub, o, sb, sa, nu);
+        // − flux at my upper face (= lower face of I+δ_b)
+        const long on = o + sb;
+        if (I[b] + 1 == N[b]) {
+          if (pb) { const long o2 = o + (long)(2 - I[b]) * sb; acc -= flux_lowerP<SCH>(f, ub, o2, sb, sa, nu, o2 + (long)(N[b] - 4) * sb); }   // Φ[CIj(j,I,2)] :62
+          else acc += flux_upperR<SCH>(f, ub, on, sb, sa, nu);
+        } else acc -= flux_inner<SCH>(f, ub, on, sb, sa, nu);
+      }
+    }
+    r[(long)a * g.cs + o] = acc;
+  }
+  // Quirk Q1: Φ≡σ keeps the fluxes of the LAST pass that covered a cell; interior values are
+  // overwritten by div/flux_out later, so only upper-ghost cells matter for CFL's maximum(σ).  Reproduce them.
+  if (Phi != nullptr && all_ge2) {
+    bool ghost = false;
+    for (int c = 0; c < D; c++) ghost = ghost || (I[c] == N[c]);
+    if (ghost) {
+      const int a = D - 1;
+      const float* __restrict__ f = u + (long)a * g.cs;
+      for (int b = D - 1; b >= 0; b--) {
+        const bool pb = (per >> b) & 1u;
+        const bool covered = (I[b] >= 3 && I[b] <= N[b] - 1) || (pb && I[b] == 2);
+        if (!covered) continue;
+        const float* __restrict__ ub = u + (long)b * g.cs;
+        Phi[o] = (I[b] == 2) ? flux_lowerP<SCH>(f, ub, o, st[b], st[a], nu, o + (long)(N[b] - 4) * st[b]) : flux_inner<SCH>(f, ub, o, st[b], st[a], nu);
+        break;
+      }
+    }
+  }
+}
+
+// BDIM!  src/Flow.jl:176-180 (+ scale_u! :211-214 folded in through pre/post)
+// pass A: f = u⁰ + dt f − V on ALL cells
+__global__ void k_bdim_f(GridX g, float* __restrict__ f, const float* __restrict__ u0, const float* __restrict__ V, float dt, long n) {
+  for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (long)gridDim.x * WL_BLOCK) {
+    const float v = V ? V[q] : 0.f;
+    f[q] = u0[q] + dt * f[q] - v;
+  }
+}
+// pass B: u[I,i] = (u*pre + (μddn(I,μ₁,f) + V + μ₀ f)) * post   on the interior
+template <int D>
+__global__ void k_bdim_u(GridX g, float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ V, const float* __restrict__ mu0, const float* __restrict__ mu1,
+                         float pre, float post, int scale_after) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long st[3] = {1, g.sy, g.sz};
+  for (int a = 0; a < D; a++) {
+    const long oa = (long)a * g.cs + o;
+    float s = 0.f;
+    if (mu1) {
+      for (int b = 0; b < D; b++) s += mu1[(long)(a + b * D) * g.cs + o] * (f[oa + st[b]] - f[oa - st[b]]);     // μddn :20-26
+    }
+    const float x = (s / 2 + (V ? V[oa] : 0.f)) + mu0[oa] * f[oa];
+    float un = (pre == 0.f) ? x : (u[oa] * pre + x);
+    if (scale_after) un = un * post;
+    u[oa] = un;
+  }
+}
+// NoBody fast path (μ₁≡0, V≡0): both passes in one kernel over all cells
+template <int D>
+__global__ void k_bdim_nobody(GridX g, float* __restrict__ u, const float* __restrict__ u0, float* __restrict__ f, const float* __restrict__ mu0, float dt, float pre, float post,
+                              int scale_after) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = (int)blockIdx.y;
+  const long o = m + (long)k * g.sz;
+  bool in = interior_ij(g, i, j);
+  if (D == 3) in = in && k >= g.k0 && k < g.k1;
+  for (int a = 0; a < D; a++) {
+    const long oa = (long)a * g.cs + o;
+    const float fn = u0[oa] + dt * f[oa] - 0.f;
+    f[oa] = fn;
+    if (in) {
+      const float x = (0.f / 2 + 0.f) + mu0[oa] * fn;
+      float un = (pre == 0.f) ? x : (u[oa] * pre + x);
+      if (scale_after) un = un * post;
+      u[oa] = un;
+    }
+  }
+}
+template <int D>
+__global__ void k_scale_u(GridX g, float* __restrict__ u, float sc) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  for (int a = 0; a < D; a++) u[(long)a * g.cs + o] *= sc;
+}
+
+// z = div(I,u)  src/Flow.jl:13-19,225 ; optional fused x *= dt over ALL cells (x may be NULL)
+template <int D>
+__global__ void k_div(GridX g, float* __restrict__ z, float* __restrict__ x, const float* __restrict__ u, float dt) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = (int)blockIdx.y;
+  const long o = m + (long)k * g.sz;
+  if (x) x[o] = x[o] * dt;
+  bool in = interior_ij(g, i, j);
+  if (D == 3) in = in && k >= g.k0 && k < g.k1;
+  if (!in) return;
+  float s = 0.f;
+  s += u[o + 1] - u[o];
+  s += u[g.cs + o + g.sy] - u[g.cs + o];
+  if (D == 3) s += u[2 * g.cs + o + g.sz] - u[2 * g.cs + o];
+  z[o] = s;
+}
+// u[I,i] -= L[I,i]*(x[I]-x[I-δᵢ])   src/Flow.jl:227-229
+template <int D>
+__global__ void k_project(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const float xc = x[o];
+  u[o] -= L[o] * (xc - x[o - 1]);
+  u[g.cs + o] -= L[g.cs + o] * (xc - x[o - g.sy]);
+  if (D == 3) u[2 * g.cs + o] -= L[2 * g.cs + o] * (xc - x[o - g.sz]);
+}
+// CFL: σ = flux_out on the interior; block max over ALL cells of σ (ghost planes keep stale Φ — quirk Q1)  src/Flow.jl:234-244
+template <int D>
+__global__ void k_cfl(GridX g, const float* __restrict__ u, float* __restrict__ sigma, float* __restrict__ pmax, int kfirst, int klast) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  float mx = -INFINITY;
+  if (cell_ij(g, m, i, j)) {
+    const bool inij = interior_ij(g, i, j);
+    for (int k = kfirst + blockIdx.y; k < klast; k += gridDim.y) {
+      const long o = m + (long)k * g.sz;
+      bool in = inij;
+      if (D == 3) in = in && k >= g.k0 && k < g.k1;
+      float s;
+      if (in) {
+        s = 0.f;
+        s += (fmaxf(0.f, u[o + 1]) + fmaxf(0.f, -u[o]));
+        s += (fmaxf(0.f, u[g.cs + o + g.sy]) + fmaxf(0.f, -u[g.cs + o]));
+        if (D == 3) s += (fmaxf(0.f, u[2 * g.cs + o + g.sz]) + fmaxf(0.f, -u[2 * g.cs + o]));
+        sigma[o] = s;
+      } else s = sigma[o];
+      mx = fmaxf(mx, s);
+    }
+  }
+  mx = block_max(mx);
+  if (threadIdx.x == 0) pmax[(long)blockIdx.y * gridDim.x + blockIdx.x] = mx;
+}
+
+// BC!(a,U,saveexit,perdir) for tuple U — all faces and components in ONE launch.   src/core.jl:200-219
+// The reference applies (i outer, j inner) face updates sequentially; the value a cell ends with is set by the
+// LAST direction j that touches it, fed from a source already processed by the lower directions.  resolve()
+// walks j = D..1 accordingly; the final source cell lies on no BC plane, so nothing it reads is written here.
+template <int D>
+__device__ __forceinline__ bool bc_touched(const int* I, const int* N, int a, int saveexit, unsigned per) {
+  for (int b = 0; b < D; b++) {
+    const bool pb = (per >> b) & 1u;
+    if (pb) { if (I[b] == 1 || I[b] == N[b]) return true; }
+    else if (a == b) { if (I[b] == 1 || I[b] == 2 || (I[b] == N[b] && !(saveexit && a == 0))) return true; }
+    else { if (I[b] == 1 || I[b] == N[b]) return true; }
+  }
+  return false;
+}
+template <int D>
+__global__ void k_bc_vec(GridX g, float* __restrict__ a_, float U0, float U1, float U2, int saveexit, unsigned per, int zwalls) {
+  // blockIdx.y = plane id: dir d = id/3, which = id%3 -> Julia index {1,2,N_d}
+  const int pid = blockIdx.y, d = pid / 3, which = pid % 3;
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
+  const float U[3] = {U0, U1, U2};
+  // enumerate the plane: the two other dims
+  const int d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+  const int n1 = (d1 == 0) ? g.nx : g.ny;
+  const long cnt = (long)n1 * ((D == 3) ? ((d2 == 1) ? g.ny : g.nz) : 1);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  int loc[3] = {0, 0, 0};   // LOCAL 0-based coords
+  loc[d1] = (int)(q % n1);
+  if (D == 3) loc[d2] = (int)(q / n1);
+  int Id = (which == 0) ? 1 : (which == 1 ? 2 : N[d]);
+  int I[3];                 // Julia GLOBAL indices
+  if (d == 2) { // z plane: only on ranks that hold that physical plane
+    const int kl = Id - 1 - g.gk; if (kl < 0 || kl >= g.nz) return; loc[2] = kl;
+    if (!zwalls) return;
+  } else loc[d] = Id - 1;
+  I[0] = loc[0] + 1; I[1] = loc[1] + 1; I[2] = (D == 3) ? g.gk + loc[2] + 1 : 1;
+  if (D == 3 && d != 2) {   // x/y planes: skip halo planes owned by a neighbour rank (filled by the halo exchange)
+    const int K = I[2];
+    const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || K == 1 || K == N[2];
+    if (!owned) return;
+  }
+  const long o = (long)loc[0] + (long)loc[1] * g.sy + (long)loc[2] * g.sz;
+  for (int a = 0; a < D; a++) {
+    if (!bc_touched<D>(I, N, a, saveexit, per)) continue;
+    int J[3] = {I[0], I[1], I[2]};
+    bool dirichlet = false;
+    for (int b = D - 1; b >= 0; b--) {
+      const bool pb = (per >> b) & 1u;
+      if (pb) { if (J[b] == 1) J[b] = N[b] - 1; else if (J[b] == N[b]) J[b] = 2; }
+      else if (a == b) { if (J[b] == 1 || J[b] == 2 || (J[b] == N[b] && !(saveexit && a == 0))) { dirichlet = true; break; } }
+      else { if (J[b] == 1) J[b] = 2; else if (J[b] == N[b]) J[b] = N[b] - 1; }
+    }
+    float v;
+    if (dirichlet) v = U[a];
+    else {
+      const long os = (long)(J[0] - 1) + (long)(J[1] - 1) * g.sy + ((D == 3) ? (long)(J[2] - 1 - g.gk) * g.sz : 0);
+      v = a_[(long)a * g.cs + os];
+    }
+    a_[(long)a * g.cs + o] = v;
+  }
+}
+// perBC!(a,perdir) for a scalar   src/core.jl:239-243  (same last-direction-wins resolution)
+template <int D>
+__global__ void k_bc_per_scalar(GridX g, float* __restrict__ a_, unsigned per) {
+  const int pid = blockIdx.y, d = pid / 2, which = pid % 2;
+  if (!((per >> d) & 1u)) return;
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
+  const int d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+  const int n1 = (d1 == 0) ? g.nx : g.ny;
+  const long cnt = (long)n1 * ((D == 3) ? ((d2 == 1) ? g.ny : g.nz) : 1);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  int loc[3] = {0, 0, 0};
+  loc[d1] = (int)(q % n1);
+  if (D == 3) loc[d2] = (int)(q / n1);
+  const int Id = which == 0 ? 1 : N[d];
+  if (d == 2) { const int kl = Id - 1 - g.gk; if (kl < 0 || kl >= g.nz) return; loc[2] = kl; } else loc[d] = Id - 1;
+  int J[3] = {loc[0] + 1, loc[1] + 1, (D == 3) ? g.gk + loc[2] + 1 : 1};
+  const long o = (long)loc[0] + (long)loc[1] * g.sy + (long)loc[2] * g.sz;
+  for (int b = D - 1; b >= 0; b--) {
+    if (!((per >> b) & 1u)) continue;
+    if (J[b] == 1) J[b] = N[b] - 1; else if (J[b] == N[b]) J[b] = 2;
+  }
+  const long os = (long)(J[0] - 1) + (long)(J[1] - 1) * g.sy + ((D == 3) ? (long)(J[2] - 1 - g.gk) * g.sz : 0);
+  a_[o] = a_[os];
+}
+
+inline unsigned grid1d(size_t n) { size_t b = (n + WL_BLOCK - 1) / WL_BLOCK; if (b > 8192) b = 8192; if (b < 1) b = 1; return (unsigned)b; }
+}  // namespace
+
+#define DSEL(D, KERN, ...)                                                           \
+  do { if ((D) == 3) hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); else hipLaunchKernelGGL(KERN<2>, __VA_ARGS__); } while (0)
+
+namespace wl {
+int fill(float* a, float v, size_t n, hipStream_t s) {
+  if (v == 0.f) { WL_HIP(hipMemsetAsync(a, 0, n * sizeof(float), s)); return 0; }
+  hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, a, v, n); WL_LAUNCH_CHECK(); return 0;
+}
+int scale(float* a, float sc, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_scale, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, a, sc, n); WL_LAUNCH_CHECK(); return 0; }
+int div_scalar(float* a, float sc, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_divs, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, a, sc, n); WL_LAUNCH_CHECK(); return 0; }
+int sum_dev(const float* a, size_t n, const RedWs& ws, int slot, hipStream_t s) {
+  const unsigned nb = grid1d(n);
+  hipLaunchKernelGGL(k_red_sum, dim3(nb), dim3(WL_BLOCK), 0, s, a, n, ws.pa);
+  hipLaunchKernelGGL(k_fin_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)nb, ws.res_d + slot);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int l1_linf_dev(const float* a, size_t n, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
+  const unsigned nb = grid1d(n);
+  hipLaunchKernelGGL(k_red_l1_linf, dim3(nb), dim3(WL_BLOCK), 0, s, a, n, ws.pa, ws.pm);
+  hipLaunchKernelGGL(k_fin_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)nb, ws.res_d + slot_d, ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int max_dev(const float* a, size_t n, const RedWs& ws, int slot_f, hipStream_t s) {
+  const unsigned nb = grid1d(n);
+  hipLaunchKernelGGL(k_red_max, dim3(nb), dim3(WL_BLOCK), 0, s, a, n, ws.pm);
+  hipLaunchKernelGGL(k_fin_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)nb, ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int dot_dev(const float* a, const float* b, size_t n, const RedWs& ws, int slot, hipStream_t s) {
+  const unsigned nb = grid1d(n);
+  hipLaunchKernelGGL(k_red_dot, dim3(nb), dim3(WL_BLOCK), 0, s, a, b, n, ws.pa);
+  hipLaunchKernelGGL(k_fin_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)nb, ws.res_d + slot);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s) {
+  WlCtx& c = wl_ctx();
+  if (nd > 0) WL_HIP(hipMemcpyAsync(c.h_d, ws.res_d, sizeof(double) * (size_t)nd, hipMemcpyDeviceToHost, s));
+  if (nf > 0) WL_HIP(hipMemcpyAsync(c.h_f, ws.res_f, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost, s));
+  WL_HIP(hipStreamSynchronize(s));
+  for (int q = 0; q < nd; q++) hd[q] = c.h_d[q];
+  for (int q = 0; q < nf; q++) hf[q] = c.h_f[q];
+  return 0;
+}
+
+int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per, hipStream_t s) {
+  // largest plane cross-section decides grid.x
+  long cmax = (long)g.ny * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > (long)g.nx * (g.D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > g.sz ? cmax : g.sz;
+  const bool dist = (g.D == 3) && (g.nz != g.gnz);
+  const int zwalls = (g.D == 3) ? ((dist && ((per >> 2) & 1u)) ? 0 : 1) : 0;
+  dim3 grid((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)(3 * g.D), 1);
+  DSEL(g.D, k_bc_vec, grid, dim3(WL_BLOCK), 0, s, g, a, U[0], U[1], g.D == 3 ? U[2] : 0.f, saveexit, per, zwalls);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s) {
+  if (!per) return 0;
+  long cmax = (long)g.ny * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > (long)g.nx * (g.D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > g.sz ? cmax : g.sz;
+  unsigned p = per;
+  if (g.D == 3 && g.nz != g.gnz) p &= ~4u;   // distributed periodic z is a halo exchange, not a local copy
+  dim3 grid((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)(2 * g.D), 1);
+  DSEL(g.D, k_bc_per_scalar, grid, dim3(WL_BLOCK), 0, s, g, a, p);
+  WL_LAUNCH_CHECK(); return 0;
+}
+
+template <int D>
+static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
+  // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes)
+  int kfirst = 0, klast = 1;
+  if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  dim3 grid = wl_plane_grid(g, klast - kfirst);
+  switch (scheme) {
+    case WL_QUICK: hipLaunchKernelGGL((k_conv_diff<D, WL_QUICK>), grid, dim3(WL_BLOCK), 0, s, g, r, u, Phi, nu, per, kfirst); break;
+    case WL_VANLEER: hipLaunchKernelGGL((k_conv_diff<D, WL_VANLEER>), grid, dim3(WL_BLOCK), 0, s, g, r, u, Phi, nu, per, kfirst); break;
+    case WL_CDS: hipLaunchKernelGGL((k_conv_diff<D, WL_CDS>), grid, dim3(WL_BLOCK), 0, s, g, r, u, Phi, nu, per, kfirst); break;
+    default: wl_set_error("unknown scheme"); return WL_EINVAL;
+  }
+  WL_LAUNCH_CHECK(); return 0;
+}
+int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
+  return g.D == 3 ? conv_diff_launch<3>(r, u, Phi, g, nu, per, scheme, s) : conv_diff_launch<2>(r, u, Phi, g, nu, per, scheme, s);
+}
+int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s) {
+  const int scale_after = (post != 1.f) ? 1 : 0;
+  if (!V && !mu1) {
+    DSEL(g.D, k_bdim_nobody, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, u, u0, f, mu0, dt, pre, post, scale_after);
+  } else {
+    const long n = g.cs * g.D;
+    hipLaunchKernelGGL(k_bdim_f, dim3(grid1d((size_t)n)), dim3(WL_BLOCK), 0, s, g, f, u0, V, dt, n);
+    DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, scale_after);
+  }
+  WL_LAUNCH_CHECK(); return 0;
+}
+int scale_u(float* u, const GridX& g, float sc, hipStream_t s) { DSEL(g.D, k_scale_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, sc); WL_LAUNCH_CHECK(); return 0; }
+int div(float* z, const float* u, const GridX& g, hipStream_t s) { DSEL(g.D, k_div, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, z, (float*)nullptr, u, 1.f); WL_LAUNCH_CHECK(); return 0; }
+int div_scale(float* z, float* x, const float* u, const GridX& g, float dt, hipStream_t s) { DSEL(g.D, k_div, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, z, x, u, dt); WL_LAUNCH_CHECK(); return 0; }
+int project(float* u, const float* L, const float* x, const GridX& g, hipStream_t s) { DSEL(g.D, k_project, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, L, x); WL_LAUNCH_CHECK(); return 0; }
+int cfl_dev(const float* u, float* sigma, const GridX& g, const RedWs& ws, int slot_f, hipStream_t s) {
+  int kfirst = 0, klast = 1;
+  if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  const long bx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
+  long by = WL_MAXPART / bx; if (by < 1) by = 1; if (by > klast - kfirst) by = klast - kfirst;
+  dim3 grid((unsigned)bx, (unsigned)by, 1);
+  DSEL(g.D, k_cfl, grid, dim3(WL_BLOCK), 0, s, g, u, sigma, ws.pm, kfirst, klast);
+  hipLaunchKernelGGL(k_fin_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)(grid.x * grid.y), ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
+}  // namespace wl

@@ -1,0 +1,26 @@
+// MultiLevelPoisson handle (struct src/MultiLevelPoisson.jl:61-77) — internal C++ definition behind `wl_mg`.
+#pragma once
+#include <vector>
+
+#include "wl_common.hpp"
+
+struct wl_mg {
+  struct Level {            // one `Poisson` (src/Poisson.jl:22-39)
+    wl_grid g; GridX x_;
+    float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
+  };
+  std::vector<Level> lv;
+  std::vector<int16_t> n;   // pois.n :66
+  unsigned perdir = 0;
+  float* slab = nullptr;    // owns r,ϵ,D,iD of every level and L,x,z of the coarse levels
+  void* red = nullptr;      // reduction workspace
+  RedWs ws;
+  std::vector<double> log_r1, log_rinf, log_w;
+
+  int build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels);
+  ~wl_mg();
+  int update(hipStream_t s);
+  int smooth(int l, int it, float w, hipStream_t s);
+  int vcycle(int l, float w, hipStream_t s);
+  int solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s);
+};

@@ -1,0 +1,321 @@
+// Poisson / multigrid leaf kernels for gfx950.  Reference semantics: /root/reference/src/Poisson.jl,
+// src/MultiLevelPoisson.jl (file:line per kernel).  All kernels: one thread per cell, linear over an
+// x-y plane (coalesced, ghosts masked), blockIdx.y walks z planes.  Arithmetic order follows the
+// reference statement by statement (compiled with -ffp-contract=off) so that element-wise results
+// are bit-identical to the CPU restatement; only reductions differ in association order.
+#include "wl_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ bool cell_ij(const GridX& g, long m, int& i, int& j) {
+  if (m >= g.sz) return false;
+  j = (int)(m / g.nx);
+  i = (int)(m - (long)j * g.nx);
+  return true;
+}
+__device__ __forceinline__ bool interior_ij(const GridX& g, int i, int j) { return i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2; }
+
+// mult(I,L,D,x)   src/Poisson.jl:70-76
+template <int D>
+__device__ __forceinline__ float Ax(const GridX& g, long o, const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ x) {
+  float s = x[o] * Dg[o];
+  s += (x[o - 1] * L[o] + x[o + 1] * L[o + 1]);
+  s += (x[o - g.sy] * L[g.cs + o] + x[o + g.sy] * L[g.cs + o + g.sy]);
+  if (D == 3) s += (x[o - g.sz] * L[2 * g.cs + o] + x[o + g.sz] * L[2 * g.cs + o + g.sz]);
+  return s;
+}
+
+// set_diag!   src/Poisson.jl:43-55
+template <int D>
+__global__ void k_set_diag(GridX g, float* __restrict__ Dg, float* __restrict__ iD, const float* __restrict__ L) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  float s = 0.f;
+  s -= (L[o] + L[o + 1]);
+  s -= (L[g.cs + o] + L[g.cs + o + g.sy]);
+  if (D == 3) s -= (L[2 * g.cs + o] + L[2 * g.cs + o + g.sz]);
+  Dg[o] = s;
+  iD[o] = (s == 0.f) ? s : 1.0f / s;
+}
+
+// mult!   src/Poisson.jl:63-69 (interior only; caller zero-fills z first)
+template <int D>
+__global__ void k_mult(GridX g, float* __restrict__ z, const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ x) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  z[o] = Ax<D>(g, o, L, Dg, x);
+}
+
+// residual!  r = iD==0 ? 0 : z - A x, with block partial sums of r   src/Poisson.jl:92-95
+template <int D>
+__global__ void k_residual(GridX g, float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ L,
+                           const float* __restrict__ Dg, const float* __restrict__ iD, double* __restrict__ part) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  double acc = 0.0;
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) {
+      const long o = m + (long)k * g.sz;
+      const float v = (iD[o] == 0.f) ? 0.f : z[o] - Ax<D>(g, o, L, Dg, x);
+      r[o] = v;
+      acc += (double)v;
+    }
+  }
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+// deterministic second stage: res_d[slot] = Σ partials
+__global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
+  double a = 0.0;
+  for (int q = threadIdx.x; q < n; q += WL_BLOCK) a += part[q];
+  a = block_sum(a);
+  if (threadIdx.x == 0) *out = a;
+}
+__global__ void k_final_sum_max(const double* __restrict__ part, const float* __restrict__ pmax, int n, double* __restrict__ out_s, float* __restrict__ out_m) {
+  double a = 0.0; float mx = -INFINITY;
+  for (int q = threadIdx.x; q < n; q += WL_BLOCK) { a += part[q]; mx = fmaxf(mx, pmax[q]); }
+  a = block_sum(a);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) { *out_s = a; *out_m = mx; }
+}
+__global__ void k_final_max(const float* __restrict__ pmax, int n, float* __restrict__ out_m) {
+  float mx = -INFINITY;
+  for (int q = threadIdx.x; q < n; q += WL_BLOCK) mx = fmaxf(mx, pmax[q]);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) *out_m = mx;
+}
+// s = Σr/N ; if |s| > 2eps(Float32): r -= s    src/Poisson.jl:95-97   (predicate evaluated on device: no host sync)
+__global__ void k_mean_shift(GridX g, float* __restrict__ r, const double* __restrict__ sum, double n_inside) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  // Julia: sum(p.r) is Float32 (pairwise); s = that / length(inside).  We round the double sum to Float32 first.
+  const float s = (float)(*sum) / (float)n_inside;
+  if (fabsf(s) <= 2.f * 1.1920929e-7f) return;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  r[o] = r[o] - s;
+}
+// L₁ = Σ|r|, L∞ = max|r| over the interior (ghosts of r are identically zero)   src/Poisson.jl:190-191
+__global__ void k_norms(GridX g, const float* __restrict__ r, double* __restrict__ part, float* __restrict__ pmax) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  double acc = 0.0; float mx = 0.f;
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) {
+      const float v = fabsf(r[m + (long)k * g.sz]);
+      acc += (double)v; mx = fmaxf(mx, v);
+    }
+  }
+  acc = block_sum(acc);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) { const long b = (long)blockIdx.y * gridDim.x + blockIdx.x; part[b] = acc; pmax[b] = mx; }
+}
+
+// increment!  r -= ω A ϵ ; x += ω ϵ      src/Poisson.jl:100-104
+template <int D>
+__global__ void k_increment(GridX g, float* __restrict__ r, float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ L,
+                            const float* __restrict__ Dg, float w) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  r[o] = r[o] - w * Ax<D>(g, o, L, Dg, eps);
+  x[o] = x[o] + w * eps[o];
+}
+
+// ϵ = r·iD    src/Poisson.jl:112,142
+__global__ void k_gs_init(GridX g, float* __restrict__ eps, const float* __restrict__ r, const float* __restrict__ iD) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  eps[o] = r[o] * iD[o];
+}
+
+// one colour of red–black Gauss–Seidel: gauss_rb / half_rangek   src/Poisson.jl:116-132,145
+// colour rule: sweep k₀ updates the cells whose Julia (1-based, GLOBAL) index sum has the
+// parity of k₀+1, i.e. (i+j+K + D + k₀) ODD with 0-based global indices.  Pairs are formed along the LAST
+// dimension, so when that extent (with ghosts) is odd the last interior layer is never visited (quirk Q4).
+template <int D>
+__global__ void k_gs_sweep(GridX g, float* __restrict__ eps, const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ iD, int kk0) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const int k = g.k0 + blockIdx.y;
+  const int K = (D == 3) ? g.gk + k : 0;
+  if (((i + j + K + D + kk0) & 1) == 0) return;
+  // Q4: last dimension index (1-based) must be <= 2*(Ng÷2)-1
+  if (D == 3) { if (K + 1 > 2 * (g.gnz / 2) - 1) return; } else { if (j + 1 > 2 * (g.ny / 2) - 1) return; }
+  const long o = m + (long)k * g.sz;
+  float s = r[o];
+  s -= (eps[o - 1] * L[o] + eps[o + 1] * L[o + 1]);
+  s -= (eps[o - g.sy] * L[g.cs + o] + eps[o + g.sy] * L[g.cs + o + g.sy]);
+  if (D == 3) s -= (eps[o - g.sz] * L[2 * g.cs + o] + eps[o + g.sz] * L[2 * g.cs + o + g.sz]);
+  eps[o] = s * iD[o];
+}
+
+// restrict!  a[I] = Σ_{J∈up(I,c)} b[J]   src/MultiLevelPoisson.jl:6,13-19,49  (children summed x fastest, like CartesianIndices)
+template <int D>
+__global__ void k_restrict(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(gc, m, i, j) || !interior_ij(gc, i, j)) return;
+  const int k = gc.k0 + blockIdx.y;
+  // 0-based: coarse i (>=1) has fine children 2i-1, 2i  (Julia: 2I-2 : 2I-1)
+  const int fi = cx ? 2 * i - 1 : i, fj = cy ? 2 * j - 1 : j;
+  int fk = 0;
+  if (D == 3) { const int K = gc.gk + k; const int FK = cz ? 2 * K - 1 : K; fk = FK - gf.gk; }
+  float s = 0.f;
+  for (int c = 0; c <= (D == 3 ? cz : 0); c++)
+    for (int bb = 0; bb <= cy; bb++)
+      for (int aa = 0; aa <= cx; aa++) s += b[(long)(fi + aa) + (long)(fj + bb) * gf.sy + (long)(fk + c) * gf.sz];
+  a[m + (long)k * gc.sz] = s;
+}
+// prolongate!  a[I] = b[down(I,c)]   src/MultiLevelPoisson.jl:7,50
+template <int D>
+__device__ __forceinline__ long down_off(const GridX& gf, const GridX& gc, int i, int j, int k, int cx, int cy, int cz) {
+  // 0-based: down(i) = (i+1)/2 when coarsened  (Julia (I+2)÷2 with I=i+1 -> 0-based (i+3)/2-1 = (i+1)/2)
+  const int ci = cx ? (i + 1) / 2 : i, cj = cy ? (j + 1) / 2 : j;
+  long o = (long)ci + (long)cj * gc.sy;
+  if (D == 3) { const int K = gf.gk + k; const int CK = cz ? (K + 1) / 2 : K; o += (long)(CK - gc.gk) * gc.sz; }
+  return o;
+}
+template <int D>
+__global__ void k_prolongate(GridX gf, GridX gc, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(gf, m, i, j) || !interior_ij(gf, i, j)) return;
+  const int k = gf.k0 + blockIdx.y;
+  a[m + (long)k * gf.sz] = b[down_off<D>(gf, gc, i, j, k, cx, cy, cz)];
+}
+// prolongate! + increment! fused (Vcycle! :99-100): ϵ_f = x_c[down(I)] on the interior, ghost ϵ_f read from memory
+template <int D>
+__global__ void k_prolong_increment(GridX gf, GridX gc, float* __restrict__ r, float* __restrict__ x, float* __restrict__ eps, const float* __restrict__ xc,
+                                    const float* __restrict__ L, const float* __restrict__ Dg, int cx, int cy, int cz, float w, int write_eps) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(gf, m, i, j) || !interior_ij(gf, i, j)) return;
+  const int k = gf.k0 + blockIdx.y;
+  const long o = m + (long)k * gf.sz;
+  auto E = [&](int ii, int jj, int kk, long oo) -> float {
+    bool in = ii >= 1 && ii <= gf.nx - 2 && jj >= 1 && jj <= gf.ny - 2;
+    if (D == 3) { const int K = gf.gk + kk; in = in && K >= 1 && K <= gf.gnz - 2; }
+    return in ? xc[down_off<D>(gf, gc, ii, jj, kk, cx, cy, cz)] : eps[oo];
+  };
+  const float e0 = xc[down_off<D>(gf, gc, i, j, k, cx, cy, cz)];
+  float s = e0 * Dg[o];
+  s += (E(i - 1, j, k, o - 1) * L[o] + E(i + 1, j, k, o + 1) * L[o + 1]);
+  s += (E(i, j - 1, k, o - gf.sy) * L[gf.cs + o] + E(i, j + 1, k, o + gf.sy) * L[gf.cs + o + gf.sy]);
+  if (D == 3) s += (E(i, j, k - 1, o - gf.sz) * L[2 * gf.cs + o] + E(i, j, k + 1, o + gf.sz) * L[2 * gf.cs + o + gf.sz]);
+  r[o] = r[o] - w * s;
+  x[o] = x[o] + w * e0;
+  if (write_eps) eps[o] = e0;
+}
+// restrictL!  a[I,i] = restrictL(I,i,b,c)   src/MultiLevelPoisson.jl:9-11,20-26,45  (BC!(a,0) applied afterwards by bc_vec)
+template <int D>
+__global__ void k_restrictL(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(gc, m, i, j) || !interior_ij(gc, i, j)) return;
+  const int k = gc.k0 + blockIdx.y;
+  const int c[3] = {cx, cy, (D == 3) ? cz : 0};
+  int f0[3] = {cx ? 2 * i - 1 : i, cy ? 2 * j - 1 : j, 0};
+  if (D == 3) { const int K = gc.gk + k; f0[2] = (cz ? 2 * K - 1 : K) - gf.gk; }
+  for (int n = 0; n < D; n++) {
+    // faces with normal n: only the first child index along n (Julia 2I-2), both children in the other coarsened dirs
+    int hi[3] = {c[0], c[1], c[2]};
+    hi[n] = 0;
+    float s = 0.f;
+    for (int cc = 0; cc <= hi[2]; cc++)
+      for (int bb = 0; bb <= hi[1]; bb++)
+        for (int aa = 0; aa <= hi[0]; aa++) s += b[(long)n * gf.cs + (long)(f0[0] + aa) + (long)(f0[1] + bb) * gf.sy + (long)(f0[2] + cc) * gf.sz];
+    a[(long)n * gc.cs + m + (long)k * gc.sz] = c[n] ? s / 2 : s;
+  }
+}
+
+inline int red_planes(const GridX& g, int nplanes) {  // cap total blocks at WL_MAXPART
+  const long bx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
+  long by = WL_MAXPART / bx; if (by < 1) by = 1;
+  return (int)(by < nplanes ? by : nplanes);
+}
+inline void mask_of(const GridX& fine, const GridX& coarse, int& cx, int& cy, int& cz) {
+  cx = coarse.nx < fine.nx; cy = coarse.ny < fine.ny; cz = (fine.D == 3) ? (coarse.gnz < fine.gnz) : 0;
+}
+}  // namespace
+
+#define DSEL(D, KERN, ...)                                                           \
+  do { if ((D) == 3) hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); else hipLaunchKernelGGL(KERN<2>, __VA_ARGS__); } while (0)
+
+namespace wl {
+int set_diag(float* Dg, float* iD, const float* L, const GridX& g, hipStream_t s) {
+  DSEL(g.D, k_set_diag, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, Dg, iD, L);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int mult(float* z, const float* L, const float* Dg, const float* x, const GridX& g, hipStream_t s) {
+  WL_HIP(hipMemsetAsync(z, 0, sizeof(float) * (size_t)g.cs, s));
+  DSEL(g.D, k_mult, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, z, L, Dg, x);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int residual(float* r, const float* x, const float* z, const float* L, const float* Dg, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s) {
+  const int np = g.k1 - g.k0, by = red_planes(g, np);
+  dim3 grid((unsigned)((g.sz + WL_BLOCK - 1) / WL_BLOCK), (unsigned)by, 1);
+  DSEL(g.D, k_residual, grid, dim3(WL_BLOCK), 0, s, g, r, x, z, L, Dg, iD, ws.pa);
+  WL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)(grid.x * grid.y), ws.res_d + 0);
+  hipLaunchKernelGGL(k_mean_shift, wl_plane_grid(g, np), dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}));
+  WL_LAUNCH_CHECK(); return 0;
+}
+int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
+  const int np = g.k1 - g.k0, by = red_planes(g, np);
+  dim3 grid((unsigned)((g.sz + WL_BLOCK - 1) / WL_BLOCK), (unsigned)by, 1);
+  hipLaunchKernelGGL(k_norms, grid, dim3(WL_BLOCK), 0, s, g, r, ws.pa, ws.pm);
+  hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)(grid.x * grid.y), ws.res_d + slot_d, ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int increment(float* r, float* x, const float* eps, const float* L, const float* Dg, const GridX& g, float w, hipStream_t s) {
+  DSEL(g.D, k_increment, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, r, x, eps, L, Dg, w);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// Jacobi!(it=1,ω)   src/Poisson.jl:111-114
+int jacobi(float* eps, float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, bool write_eps, hipStream_t s) {
+  // two-pass form (ϵ staged in memory): exact reference order, in place, race free
+  (void)write_eps;
+  hipLaunchKernelGGL(k_gs_init, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, iD);
+  WL_LAUNCH_CHECK();
+  return increment(r, x, eps, L, Dg, g, w, s);
+}
+int gs_init(float* eps, const float* r, const float* iD, const GridX& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_gs_init, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, iD);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const GridX& g, int k0, hipStream_t s) {
+  DSEL(g.D, k_gs_sweep, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, L, iD, k0);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s) {
+  int cx, cy, cz; mask_of(gf, gc, cx, cy, cz);
+  DSEL(gc.D, k_restrict, wl_plane_grid(gc, gc.k1 - gc.k0), dim3(WL_BLOCK), 0, s, gc, gf, a, b, cx, cy, cz);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int prolongate(float* a, const GridX& gf, const float* b, const GridX& gc, hipStream_t s) {
+  int cx, cy, cz; mask_of(gf, gc, cx, cy, cz);
+  DSEL(gf.D, k_prolongate, wl_plane_grid(gf, gf.k1 - gf.k0), dim3(WL_BLOCK), 0, s, gf, gc, a, b, cx, cy, cz);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int prolong_increment(float* r, float* x, float* eps, const float* xc, const float* L, const float* Dg, const GridX& gf, const GridX& gc, float w, bool write_eps, hipStream_t s) {
+  int cx, cy, cz; mask_of(gf, gc, cx, cy, cz);
+  DSEL(gf.D, k_prolong_increment, wl_plane_grid(gf, gf.k1 - gf.k0), dim3(WL_BLOCK), 0, s, gf, gc, r, x, eps, xc, L, Dg, cx, cy, cz, w, write_eps ? 1 : 0);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int restrictL(float* a, const GridX& gc, const float* b, const GridX& gf, unsigned per, hipStream_t s) {
+  int cx, cy, cz; mask_of(gf, gc, cx, cy, cz);
+  DSEL(gc.D, k_restrictL, wl_plane_grid(gc, gc.k1 - gc.k0), dim3(WL_BLOCK), 0, s, gc, gf, a, b, cx, cy, cz);
+  WL_LAUNCH_CHECK();
+  const float zero[3] = {0.f, 0.f, 0.f};
+  return bc_vec(a, gc, zero, 0, per, s);   // BC!(a,zero,false,perdir)  :47
+}
+}  // namespace wl

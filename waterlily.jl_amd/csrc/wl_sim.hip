@@ -1,0 +1,365 @@
+// Simulation/Flow composite handle: mom_step! orchestration (src/Flow.jl:156-237) on one HIP stream,
+// plus the device-side input generators / read-outs used by the configs (TGV initial condition,
+// closed-form sphere measure!, pressure_force) and exitBC!, L₂.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "wl_common.hpp"
+#include "wl_mg.hpp"
+
+namespace {
+__device__ __forceinline__ bool cell_ij(const GridX& g, long m, int& i, int& j) {
+  if (m >= g.sz) return false;
+  j = (int)(m / g.nx);
+  i = (int)(m - (long)j * g.nx);
+  return true;
+}
+__device__ __forceinline__ bool interior_ij(const GridX& g, int i, int j) { return i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2; }
+
+// apply!(u0,u): u[I,i] = u0(i, loc(i,I))   src/Flow.jl:81-83, loc src/core.jl:177 (Float32)
+// kind 1: wall-bounded TGV κ=π/N ; kind 2: periodic TGV κ=2π/N  
+template <int D>
+__global__ void k_apply_tgv(GridX g, float* __restrict__ u, float kx, float ky, float kz) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = blockIdx.y;
+  const long o = m + (long)k * g.sz;
+  const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
+  for (int a = 0; a < D; a++) {
+    float x[3];
+    for (int c = 0; c < 3; c++) x[c] = (float)I[c] - 1.5f - ((c == a) ? 1.f : 0.f) / 2.f;
+    const double X = (double)x[0] * kx, Y = (double)x[1] * ky, Z = (D == 3) ? (double)x[2] * kz : 0.0;
+    double v;
+    if (a == 0) v = -sin(X) * cos(Y) * ((D == 3) ? cos(Z) : 1.0);
+    else if (a == 1) v = cos(X) * sin(Y) * ((D == 3) ? cos(Z) : 1.0);
+    else v = 0.0;
+    u[(long)a * g.cs + o] = (float)v;
+  }
+}
+template <int D>
+__global__ void k_apply_const(GridX g, float* __restrict__ u, float U0, float U1, float U2) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j)) return;
+  const long o = m + (long)blockIdx.y * g.sz;
+  u[o] = U0; u[g.cs + o] = U1; if (D == 3) u[2 * g.cs + o] = U2;
+}
+
+// BDIM kernel moments   src/Body.jl:54-60
+__device__ __forceinline__ float kern_(float d) { return (1 + cosf(3.14159265358979323846f * d)) / 2; }
+__device__ __forceinline__ float kern0_(float d) { return (1 + d + sinf(3.14159265358979323846f * d) / 3.14159265358979323846f) / 2; }
+__device__ __forceinline__ float kern1_(float d) { return (1 - d * d) / 4 - (d * sinf(3.14159265358979323846f * d) + (1 + cosf(3.14159265358979323846f * d)) / 3.14159265358979323846f) / (2 * 3.14159265358979323846f); }
+__device__ __forceinline__ float eps_at(float d) { d = fabsf(d); return d == 0.f ? 1.4e-45f : nextafterf(d, INFINITY) - d; }
+__device__ __forceinline__ float mu0_(float d, float e) { return d / e < -1 + sqrtf(eps_at(d)) ? 0.f : kern0_(fminf(d / e, 1.f)); }
+__device__ __forceinline__ float mu1_(float d, float e) { return e * kern1_(fminf(fmaxf(d / e, -1.f), 1.f)); }
+// measure(body,x): sphere sdf, AutoBody closed form   src/AutoBody.jl:29-37
+template <int D>
+__device__ __forceinline__ void sphere_measure(const float* x, const float* c, float R, float fastd2, float& d, float* n) {
+  float s = 0.f;
+  for (int q = 0; q < D; q++) { n[q] = 0.f; s += (x[q] - c[q]) * (x[q] - c[q]); }
+  const float rr = sqrtf(s);
+  d = rr - R;
+  if (d * d > fastd2) return;
+  float gq[3]; bool nan = false;
+  for (int q = 0; q < D; q++) { gq[q] = (x[q] - c[q]) / rr; nan = nan || isnan(gq[q]); }
+  if (nan) return;
+  float mm = 0.f; for (int q = 0; q < D; q++) mm += gq[q] * gq[q];
+  mm = sqrtf(mm); d /= mm;
+  for (int q = 0; q < D; q++) n[q] = gq[q] / mm;
+}
+// measure!(flow,body;ϵ) for the sphere: fills σ(sdf), μ₀, μ₁, V(=0) on the interior   src/Body.jl:28-48
+template <int D>
+__global__ void k_measure_sphere(GridX g, float* __restrict__ sig, float* __restrict__ mu0, float* __restrict__ mu1, float c0, float c1, float c2, float R, float e) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const int k = g.k0 + blockIdx.y;
+  const long o = m + (long)k * g.sz;
+  const float c[3] = {c0, c1, c2};
+  const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
+  float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
+  float s = 0.f; for (int q = 0; q < D; q++) s += (x[q] - c[q]) * (x[q] - c[q]);
+  const float dc = sqrtf(s) - R;
+  sig[o] = dc;
+  const float d2 = (2 + e) * (2 + e);
+  if (dc * dc < d2) {
+    for (int a = 0; a < D; a++) {
+      float xf[3]; for (int q = 0; q < 3; q++) xf[q] = x[q] - ((q == a) ? 0.5f : 0.f);
+      float di, ni[3]; sphere_measure<D>(xf, c, R, d2, di, ni);
+      di = fabsf(di) <= 0.5f ? di : copysignf(di, dc);
+      mu0[(long)a * g.cs + o] = mu0_(di, e);
+      for (int b = 0; b < D; b++) mu1[(long)(a + b * D) * g.cs + o] = mu1_(di, e) * ni[b];
+    }
+  } else if (dc < 0.f) {
+    for (int a = 0; a < D; a++) mu0[(long)a * g.cs + o] = 0.f;
+  }
+}
+// pressure_force: Σ_inside p[I]·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:116-133
+template <int D>
+__global__ void k_pforce_sphere(GridX g, const float* __restrict__ p, float c0, float c1, float c2, float R, double* __restrict__ part) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  double acc[3] = {0, 0, 0};
+  const float c[3] = {c0, c1, c2};
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) {
+      const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
+      float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
+      float d, n[3]; sphere_measure<D>(x, c, R, 1.f, d, n);
+      const float kk = kern_(fminf(fmaxf(d, -1.f), 1.f));
+      const float pv = p[m + (long)k * g.sz];
+      for (int a = 0; a < D; a++) acc[a] += (double)(pv * (n[a] * kk));
+    }
+  }
+  const long b = (long)blockIdx.y * gridDim.x + blockIdx.x, nb = (long)gridDim.x * gridDim.y;
+  for (int a = 0; a < 3; a++) { const double v = block_sum(acc[a]); if (threadIdx.x == 0) part[a * nb + b] = v; __syncthreads(); }
+}
+__global__ void k_fin3(const double* __restrict__ part, int nb, double* __restrict__ out) {
+  for (int a = 0; a < 3; a++) {
+    double s = 0.0; for (int q = threadIdx.x; q < nb; q += WL_BLOCK) s += part[(long)a * nb + q];
+    s = block_sum(s); if (threadIdx.x == 0) out[a] = s; __syncthreads();
+  }
+}
+template <int D>
+__global__ void k_l2_inside(GridX g, const float* __restrict__ a, double* __restrict__ part) {
+  int i, j;
+  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  double acc = 0.0;
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j))
+    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) { const double v = (double)a[m + (long)k * g.sz]; acc += v * v; }
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+__global__ void k_fin1(const double* __restrict__ part, int n, double* __restrict__ out) {
+  double a = 0.0; for (int q = threadIdx.x; q < n; q += WL_BLOCK) a += part[q];
+  a = block_sum(a); if (threadIdx.x == 0) *out = a;
+}
+
+// exitBC!(u,u⁰,Δt)   src/core.jl:226-233 — single-domain; face sums by one block (deterministic), all on device
+// mode 0: out[0] = Σ u[2, 2:N-1.., 1]/len (inflow) ; mode 1: out[1] = Σ u[N, ..,1]/len − out[0]
+template <int D>
+__global__ void k_exit_facesum(GridX g, const float* __restrict__ u, double* __restrict__ out, int mode) {
+  const int ny = g.ny - 2, nz = (D == 3) ? (g.nz - 2) : 1;
+  const long cnt = (long)ny * nz;
+  const int ix = (mode == 0) ? 1 : g.nx - 1;
+  double acc = 0.0;
+  for (long q = threadIdx.x; q < cnt; q += blockDim.x) {
+    const int j = 1 + (int)(q % ny), k = (D == 3) ? 1 + (int)(q / ny) : 0;
+    acc += (double)u[ix + (long)j * g.sy + (long)k * g.sz];
+  }
+  __shared__ double sh[16];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += sh[w];
+    const float mean = (float)s / (float)cnt;
+    if (mode == 0) out[0] = (double)mean; else out[1] = (double)(mean - (float)out[0]);
+  }
+}
+template <int D>
+__global__ void k_exit_update(GridX g, float* __restrict__ u, const float* __restrict__ u0, const double* __restrict__ sc, float dt, int mode) {
+  const int ny = g.ny - 2;
+  const long cnt = (long)ny * ((D == 3) ? (g.nz - 2) : 1);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  const int j = 1 + (int)(q % ny), k = (D == 3) ? 1 + (int)(q / ny) : 0;
+  const long o = (g.nx - 1) + (long)j * g.sy + (long)k * g.sz;
+  if (mode == 0) { const float U = (float)sc[0]; u[o] = u0[o] - U * dt * (u0[o] - u0[o - 1]); }
+  else u[o] -= (float)sc[1];
+}
+}  // namespace
+
+#define DSEL(D, KERN, ...)                                                           \
+  do { if ((D) == 3) hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); else hipLaunchKernelGGL(KERN<2>, __VA_ARGS__); } while (0)
+
+// ================================================================================================
+struct wl_sim {
+  wl_sim_desc d;
+  wl_grid g; GridX G;
+  float *u = nullptr, *u0 = nullptr, *f = nullptr, *p = nullptr, *sigma = nullptr, *V = nullptr, *mu0 = nullptr, *mu1 = nullptr;
+  float* own = nullptr;
+  wl_mg* mg = nullptr;
+  std::vector<float> dt;
+  ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
+
+  int bc_u(hipStream_t s) { return wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s); }
+  int exit_bc(hipStream_t s);
+  int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
+    WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s));
+    WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
+    WL_TRY(bc_u(s));
+    if (d.exitBC) WL_TRY(exit_bc(s));
+    return 0;
+  }
+  int correct(hipStream_t s) {                                                           // mom_correct! :205-210
+    WL_TRY(wl::conv_diff(f, u, sigma, G, d.nu, d.perdir_mask, d.scheme, s));
+    WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
+    return bc_u(s);
+  }
+  int project(float w, hipStream_t s) {                                                  // mom_project! :223-232
+    const float dtl = w * dt.back();
+    WL_TRY(wl::div_scale(sigma, p, u, G, dtl, s));                                       // z=div(u); x.*=dt
+    WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s));
+    WL_TRY(wl::project(u, mu0, p, G, s));
+    WL_TRY(wl::div_scalar(p, dtl, (size_t)G.cs, s));                                     // x./=dt
+    return bc_u(s);
+  }
+  int cfl(hipStream_t s) {                                                               // CFL :234-237
+    WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s));
+    float mx; WL_TRY(wl::read_results(mg->ws, nullptr, 0, &mx, 1, s));
+    dt.push_back(std::fmin(10.f, 1.0f / (mx + 5 * d.nu)));
+    return 0;
+  }
+  int mom_step(hipStream_t s) {                                                          // mom_step! :156-167
+    WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s));   // u⁰ .= u
+    WL_TRY(predict(s));
+    WL_TRY(project(1.f, s));
+    WL_TRY(correct(s));
+    WL_TRY(project(0.5f, s));
+    return cfl(s);
+  }
+};
+int wl_sim::exit_bc(hipStream_t s) {
+  double* sc = mg->ws.res_d + 4;
+  const long cnt = (long)(G.ny - 2) * (G.D == 3 ? (G.nz - 2) : 1);
+  const unsigned nb = (unsigned)((cnt + WL_BLOCK - 1) / WL_BLOCK);
+  DSEL(G.D, k_exit_facesum, dim3(1), dim3(1024), 0, s, G, u, sc, 0);
+  DSEL(G.D, k_exit_update, dim3(nb), dim3(WL_BLOCK), 0, s, G, u, u0, sc, dt.back(), 0);
+  DSEL(G.D, k_exit_facesum, dim3(1), dim3(1024), 0, s, G, u, sc, 1);
+  DSEL(G.D, k_exit_update, dim3(nb), dim3(WL_BLOCK), 0, s, G, u, u0, sc, dt.back(), 1);
+  WL_LAUNCH_CHECK(); return 0;
+}
+
+extern "C" {
+
+int wl_exit_bc(float* u, const float* u0, const wl_grid* g, float dt, void* st) {
+  WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_CHECK(g->D == 2 || g->nz == g->gnz, "exitBC! needs the whole x-exit face on one rank");
+  WL_TRY(wl_ctx_ensure());
+  const GridX G = gx(*g); hipStream_t s = wl_stream(st);
+  double* sc = wl_red_ws(wl_ctx().red).res_d + 4;
+  const long cnt = (long)(G.ny - 2) * (G.D == 3 ? (G.nz - 2) : 1);
+  const unsigned nb = (unsigned)((cnt + WL_BLOCK - 1) / WL_BLOCK);
+  DSEL(G.D, k_exit_facesum, dim3(1), dim3(1024), 0, s, G, (const float*)u, sc, 0);
+  DSEL(G.D, k_exit_update, dim3(nb), dim3(WL_BLOCK), 0, s, G, u, u0, sc, dt, 0);
+  DSEL(G.D, k_exit_facesum, dim3(1), dim3(1024), 0, s, G, (const float*)u, sc, 1);
+  DSEL(G.D, k_exit_update, dim3(nb), dim3(WL_BLOCK), 0, s, G, u, u0, sc, dt, 1);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int wl_L2_inside(const float* a, const wl_grid* g, double* out, void* st) {
+  WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
+  const GridX G = gx(*g); hipStream_t s = wl_stream(st);
+  const RedWs ws = wl_red_ws(wl_ctx().red);
+  const long bx = (G.sz + WL_BLOCK - 1) / WL_BLOCK; long by = WL_MAXPART / bx; if (by < 1) by = 1; if (by > G.k1 - G.k0) by = G.k1 - G.k0;
+  DSEL(G.D, k_l2_inside, dim3((unsigned)bx, (unsigned)by), dim3(WL_BLOCK), 0, s, G, a, ws.pa);
+  hipLaunchKernelGGL(k_fin1, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)(bx * by), ws.res_d + 0);
+  WL_LAUNCH_CHECK();
+  return wl::read_results(ws, out, 1, nullptr, 0, s);
+}
+
+int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) {
+  WL_CHECK(out && desc, "null pointer"); WL_CHECK(desc->D == 2 || desc->D == 3, "D must be 2 or 3");
+  WL_TRY(wl_ctx_ensure());
+  wl_sim* s = new wl_sim(); s->d = *desc;
+  int32_t ng[3] = {desc->dims[0] + 2, desc->dims[1] + 2, desc->D == 3 ? desc->dims[2] + 2 : 1};
+  s->g = wl_grid_single(desc->D, ng); s->G = gx(s->g);
+  const size_t nc = (size_t)s->G.cs; const int D = desc->D;
+  float** ptrs[8] = {&s->u, &s->u0, &s->f, &s->p, &s->sigma, &s->V, &s->mu0, &s->mu1};
+  float* given[8] = {desc->u, desc->u0, desc->f, desc->p, desc->sigma, desc->V, desc->mu0, desc->mu1};
+  const size_t sz[8] = {nc * D, nc * D, nc * D, nc, nc, nc * D, nc * D, nc * D * D};
+  size_t total = 0;
+  for (int q = 0; q < 8; q++) if (!given[q] && !(q == 7 && !desc->has_body) && !(q == 5 && !desc->has_body)) total += sz[q];
+  if (total) { hipError_t e = hipMalloc((void**)&s->own, total * sizeof(float)); if (e != hipSuccess) { delete s; wl_set_error("hipMalloc failed for flow arrays"); return (int)e; } (void)hipMemset(s->own, 0, total * sizeof(float)); }
+  float* pcur = s->own;
+  for (int q = 0; q < 8; q++) {
+    if (given[q]) *ptrs[q] = given[q];
+    else if ((q == 7 || q == 5) && !desc->has_body) *ptrs[q] = nullptr;
+    else { *ptrs[q] = pcur; pcur += sz[q]; }
+  }
+  s->dt.assign(1, desc->dt0);
+  // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
+  if (!desc->mu0) {
+    int rc = wl::fill(s->mu0, 1.f, nc * D, 0); const float zero[3] = {0, 0, 0};
+    if (rc == 0) rc = wl::bc_vec(s->mu0, s->G, zero, 0, desc->perdir_mask, 0);
+    if (rc != 0) { delete s; return rc; }
+  }
+  int rc = wl_mg_create(&s->mg, s->p, s->mu0, s->sigma, &s->g, desc->perdir_mask, 10);   // pois_ctor default  src/WaterLily.jl:97
+  if (rc != 0) { delete s; *out = nullptr; return rc; }
+  *out = s; return 0;
+}
+int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
+float* wl_sim_field(wl_sim* s, const char* name) {
+  const std::string n(name);
+  if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") return s->p;
+  if (n == "sigma") return s->sigma; if (n == "V") return s->V; if (n == "mu0") return s->mu0; if (n == "mu1") return s->mu1;
+  return nullptr;
+}
+wl_mg* wl_sim_pois(wl_sim* s) { return s->mg; }
+int wl_sim_grid(const wl_sim* s, wl_grid* out) { *out = s->g; return 0; }
+int wl_sim_init_flow(wl_sim* s, void* st) {                                               // Flow ctor :141-142
+  hipStream_t q = wl_stream(st);
+  WL_TRY(s->bc_u(q));
+  if (s->d.exitBC) {   // exitBC!(u,u,zero(T)): u⁰ aliases u, Δt = 0
+    const float keep = s->dt.back(); float* keep0 = s->u0;
+    s->dt.back() = 0.f; s->u0 = s->u;
+    const int rc = s->exit_bc(q);
+    s->dt.back() = keep; s->u0 = keep0;
+    if (rc != 0) return rc;
+  }
+  WL_HIP(hipMemcpyAsync(s->u0, s->u, sizeof(float) * (size_t)s->G.cs * s->d.D, hipMemcpyDeviceToDevice, q));
+  return 0;
+}
+int wl_sim_update(wl_sim* s, void* st) { return s->mg->update(wl_stream(st)); }
+int wl_sim_mom_step(wl_sim* s, void* st) { return s->mom_step(wl_stream(st)); }
+int wl_sim_dt(const wl_sim* s, float* out, int cap) { const int n = (int)s->dt.size(); for (int k = 0; k < n && k < cap; k++) out[k] = s->dt[(size_t)k]; return n; }
+double wl_sim_time(const wl_sim* s) { float t = 0.f; for (size_t k = 0; k + 1 < s->dt.size(); k++) t += s->dt[k]; return (double)t; }
+int wl_sim_phase(wl_sim* s, int phase, void* st) {
+  hipStream_t q = wl_stream(st);
+  switch (phase) {
+    case 0: WL_HIP(hipMemcpyAsync(s->u0, s->u, sizeof(float) * (size_t)s->G.cs * s->d.D, hipMemcpyDeviceToDevice, q)); return wl::scale_u(s->u, s->G, 0.f, q);
+    case 1: return s->predict(q);
+    case 2: return s->project(1.f, q);
+    case 3: return s->correct(q);
+    case 4: return s->project(0.5f, q);
+    case 5: return s->cfl(q);
+  }
+  wl_set_error("bad phase"); return WL_EINVAL;
+}
+int wl_sim_apply_ic(wl_sim* s, int kind, void* st) {
+  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
+  if (kind == 0) { DSEL(D, k_apply_const, wl_plane_grid(G, G.nz), dim3(WL_BLOCK), 0, q, G, s->u, s->d.uBC[0], s->d.uBC[1], s->d.uBC[2]); }
+  else {
+    const float two = (kind == 2) ? 2.f : 1.f;
+    const float kx = two * 3.14159265358979323846f / (float)s->d.dims[0], ky = two * 3.14159265358979323846f / (float)s->d.dims[1];
+    const float kz = (D == 3) ? two * 3.14159265358979323846f / (float)s->d.dims[2] : 0.f;
+    DSEL(D, k_apply_tgv, wl_plane_grid(G, G.nz), dim3(WL_BLOCK), 0, q, G, s->u, kx, ky, kz);
+  }
+  WL_LAUNCH_CHECK(); return 0;
+}
+int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* st) {
+  WL_CHECK(s->d.has_body && s->mu1 && s->V, "simulation was created with has_body=0");
+  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D; const size_t nc = (size_t)G.cs;
+  WL_TRY(wl::fill(s->V, 0.f, nc * D, q)); WL_TRY(wl::fill(s->mu0, 1.f, nc * D, q)); WL_TRY(wl::fill(s->mu1, 0.f, nc * D * D, q));   // Body.jl:29
+  DSEL(D, k_measure_sphere, wl_plane_grid(G, G.k1 - G.k0), dim3(WL_BLOCK), 0, q, G, s->sigma, s->mu0, s->mu1, c[0], c[1], D == 3 ? c[2] : 0.f, R, eps);
+  WL_LAUNCH_CHECK();
+  const float zero[3] = {0, 0, 0};
+  WL_TRY(wl::bc_vec(s->mu0, G, zero, 0, s->d.perdir_mask, q));                                                                     // Body.jl:49
+  WL_TRY(wl::bc_vec(s->V, G, zero, s->d.exitBC, s->d.perdir_mask, q));                                                              // Body.jl:50
+  return s->mg->update(q);                                                                                                          // WaterLily.jl:148
+}
+int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {
+  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
+  const long bx = (G.sz + WL_BLOCK - 1) / WL_BLOCK; long by = (WL_MAXPART / 3) / bx; if (by < 1) by = 1; if (by > G.k1 - G.k0) by = G.k1 - G.k0;
+  // partials need 3*nb doubles: pa and pb are contiguous (2*WL_MAXPART doubles)
+  DSEL(D, k_pforce_sphere, dim3((unsigned)bx, (unsigned)by), dim3(WL_BLOCK), 0, q, G, (const float*)s->p, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
+  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)(bx * by), s->mg->ws.res_d + 4);
+  WL_LAUNCH_CHECK();
+  WlCtx& cx = wl_ctx();
+  WL_HIP(hipMemcpyAsync(cx.h_d, s->mg->ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
+  WL_HIP(hipStreamSynchronize(q));
+  for (int a = 0; a < D; a++) out[a] = cx.h_d[a];
+  return 0;
+}
+}  // extern "C"

@@ -1,0 +1,169 @@
+"""Simulation — host-side mirror of /root/reference/src/WaterLily.jl:86-149, plus the fused composite
+handle (`wl_sim`) that bench.py times."""
+import ctypes as C
+
+import numpy as np
+
+from . import core
+from ._lib import check, lib, wl_grid, wl_sim_desc
+from .core import perdir_mask, ptr, stream
+from .flow import Flow, mom_step_
+from .poisson import MultiLevelPoisson
+
+
+class Simulation:
+    """Simulation(dims,uBC,L;U,Δt,ν,ϵ,perdir,exitBC,λ,body,T) over leaf operations (reference orchestration)."""
+
+    def __init__(self, dims, uBC, L, U=None, dt=0.25, nu=0.0, eps=1, perdir=(), u0=None, exitBC=False, lam=core.QUICK,
+                 body=None, T=np.float32):
+        if U is None:
+            U = float(np.sqrt(sum(float(v) ** 2 for v in uBC)))                  # :100
+        self.U, self.L, self.eps = float(U), float(L), eps
+        self.flow = Flow(dims, uBC, dt=dt, nu=nu, u0=u0, perdir=perdir, exitBC=exitBC, lam=lam, T=T)   # :103
+        self.body = body
+        if body is not None:
+            raise NotImplementedError("bodies go through FusedSimulation.measure_sphere_ this round")
+        self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir)   # :97,105
+
+    def sim_time(self):
+        return float(self.flow.time()) * self.U / self.L                          # :117
+
+    def sim_step_(self, t_end=None, remeasure=True, max_steps=2**31 - 1):
+        """sim_step!(sim[,t_end];remeasure,max_steps)   :128-139"""
+        if t_end is None:
+            if remeasure:
+                self.measure_()
+            mom_step_(self.flow, self.pois)
+            return
+        steps0 = len(self.flow.dt)
+        while self.sim_time() < t_end and len(self.flow.dt) - steps0 < max_steps:
+            self.sim_step_(remeasure=remeasure)
+
+    def measure_(self):
+        """measure!(sim): NoBody => only update!(pois)   :146-149 (quirk Q3: runs every step when remeasure=true)"""
+        self.pois.update_()
+
+
+class FusedSimulation:
+    """The composite path: one `wl_sim` handle holds every field in HBM and runs mom_step! (src/Flow.jl:156-167)
+    as a fixed sequence of fused HIP kernels on one stream.  This is what bench.py times."""
+
+    def __init__(self, dims, uBC, L, U=None, dt=0.25, nu=0.0, perdir=(), exitBC=False, lam=core.QUICK, has_body=False, ic="uBC", u0=None):
+        core.device()
+        D = len(dims)
+        if U is None:
+            U = float(np.sqrt(sum(float(v) ** 2 for v in uBC)))
+        self.U, self.L, self.D = float(U), float(L), D
+        self.dims = tuple(int(n) for n in dims)
+        self.Ng = tuple(n + 2 for n in self.dims)
+        d = wl_sim_desc()
+        d.D = D
+        for k in range(3):
+            d.dims[k] = self.dims[k] if k < D else 1
+            d.uBC[k] = float(uBC[k]) if k < D else 0.0
+        d.nu, d.dt0 = float(nu), float(dt)
+        d.perdir_mask, d.exitBC, d.scheme, d.has_body = perdir_mask(perdir), int(bool(exitBC)), int(lam), int(bool(has_body))
+        h = C.c_void_p()
+        check(lib().wl_sim_create(C.byref(h), C.byref(d)))
+        self._h = h
+        self.nu = float(nu)
+        self.has_body = bool(has_body)
+        if u0 is not None:
+            self.set_field("u", np.asfortranarray(u0, dtype=np.float32))
+        else:
+            check(lib().wl_sim_apply_ic(h, {"uBC": 0, "tgv": 1, "tgv_periodic": 2}[ic], stream()))
+        check(lib().wl_sim_init_flow(h, stream()))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().wl_sim_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def _shape(self, name):
+        D = self.D
+        return {"p": self.Ng, "sigma": self.Ng, "mu1": self.Ng + (D, D)}.get(name, self.Ng + (D,))
+
+    def field(self, name):
+        """`Array(flow.<name>)`"""
+        out = np.empty(self._shape(name), dtype=np.float32, order="F")
+        p = lib().wl_sim_field(self._h, name.encode())
+        if not p:
+            raise KeyError(name)
+        check(lib().wl_d2h(out.ctypes.data_as(C.c_void_p), p, out.nbytes, stream()))
+        return out
+
+    def set_field(self, name, a):
+        a = np.asfortranarray(a, dtype=np.float32)
+        assert a.shape == self._shape(name)
+        check(lib().wl_h2d(lib().wl_sim_field(self._h, name.encode()), a.ctypes.data_as(C.c_void_p), a.nbytes, stream()))
+        check(lib().wl_stream_sync(stream()))
+
+    def mom_step_(self):
+        check(lib().wl_sim_mom_step(self._h, stream()))
+
+    def phase_(self, k):
+        check(lib().wl_sim_phase(self._h, int(k), stream()))
+
+    def sim_step_(self, t_end=None, remeasure=False, max_steps=2**31 - 1):
+        if t_end is None:
+            if remeasure:
+                check(lib().wl_sim_update(self._h, stream()))
+            self.mom_step_()
+            return
+        n = 0
+        while self.sim_time() < t_end and n < max_steps:
+            self.sim_step_(remeasure=remeasure)
+            n += 1
+
+    def update_(self):
+        check(lib().wl_sim_update(self._h, stream()))
+
+    @property
+    def dt(self):
+        out = (C.c_float * 1000000)()
+        k = lib().wl_sim_dt(self._h, out, 1000000)
+        return [np.float32(v) for v in out[:k]]
+
+    def time(self):
+        return lib().wl_sim_time(self._h)
+
+    def sim_time(self):
+        return self.time() * self.U / self.L
+
+    @property
+    def pois_n(self):
+        mg = lib().wl_sim_pois(self._h)
+        out = (C.c_int16 * 65536)()
+        k = lib().wl_mg_history(mg, out, 65536)
+        return [int(v) for v in out[:k]]
+
+    def pois_level(self, name, l=0):
+        mg = lib().wl_sim_pois(self._h)
+        g = wl_grid()
+        check(lib().wl_mg_level_grid(mg, l, C.byref(g)))
+        dims = (g.nx, g.ny) if g.D == 2 else (g.nx, g.ny, g.nz)
+        shape = dims + (g.D,) if name == "L" else dims
+        out = np.empty(shape, dtype=np.float32, order="F")
+        check(lib().wl_d2h(out.ctypes.data_as(C.c_void_p), lib().wl_mg_level_field(mg, l, name.encode()), out.nbytes, stream()))
+        return out
+
+    def nlevels(self):
+        return lib().wl_mg_nlevels(lib().wl_sim_pois(self._h))
+
+    def measure_sphere_(self, center, R, eps=1.0):
+        """measure!(sim) for AutoBody(|x-c|-R): closed form on device + update!(pois)"""
+        c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
+        check(lib().wl_sim_measure_sphere(self._h, c, float(R), float(eps), stream()))
+
+    def pressure_force_sphere(self, center, R):
+        c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
+        out = (C.c_double * 3)()
+        check(lib().wl_sim_pressure_force_sphere(self._h, c, float(R), out, stream()))
+        return np.array(out[: self.D])
+
+    def sync(self):
+        check(lib().wl_stream_sync(stream()))
