@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py — cells·steps/s of WaterLily's time step (mom_step!, src/Flow.jl:156-167) on MI355X.
+
+One "step" = one mom_step! (predictor + corrector, two multigrid pressure solves, CFL) of the 3-D
+wall-bounded Taylor–Green vortex of SURVEY §8d (Float32, NoBody, remeasure=false), every field resident in
+HBM when the timed region starts.  N=1 workload: 512³ (the size BASELINE.json's metric and the ≥60 %
+smoother target are quoted on); with --gpus N the same 512³ domain is cut into N z-slabs (strong scaling).
+
+Prints ONE JSON line (rank 0): metric/value + `roofline` (dominant kernel, HIP-event timed inside the timed
+region on the launch stream) + `cpu_baseline` (the oracle — a CPU restatement of the reference algorithm,
+kind "port" — timed on this box's host cores on a bounded 128³ sample of the same workload).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ≈6.3 achievable)
+# algorithmic bytes per interior cell (SURVEY §8d / BASELINE.md §4), f32, 3-D
+BYTES_GS_SWEEP = 20.0     # one colour sweep as its own pass: R ½r,½iD,L₁₋₃,½ϵ  W ½ϵ
+BYTES_SMOOTH_OP = 40.0    # GaussSeidelRB!(it=4) as ONE operation: R r,iD,L₁₋₃,D,x  W ϵ,r,x
+
+
+def cpu_baseline(n=128, warm=2, steps=None, budget_s=12.0):
+    """Time the oracle (CPU restatement, OpenMP = analogue of the reference's KA CPU threads) on the same
+    TGV workload at 128³.  Bounded: stops after `budget_s` seconds of timed work."""
+    import math
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    L = orc.lib(omp=True)
+    # threads = the CPUs this process may actually use (cgroup quota / affinity), not the host's logical count
+    cores = min(L.wlo_max_threads(), len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per))))
+    except Exception:
+        pass
+    cores = int(os.environ.get("WL_CPU_THREADS", cores))
+    L.wlo_set_threads(cores)
+    sim = orc.Simulation((n, n, n), (0, 0, 0), n, U=1, nu=n / 1600.0, T=np.float32, omp=True)
+    kap = math.pi / n
+    u = sim.u
+    ax = np.arange(n + 2, dtype=np.float32) + np.float32(1) - np.float32(1.5)     # loc(0,I) per axis
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    h = np.float32(0.5)
+    u[..., 0] = (-np.sin(kap * (X - h).astype(np.float64)) * np.cos(kap * Y.astype(np.float64)) * np.cos(kap * Z.astype(np.float64))).astype(np.float32)
+    u[..., 1] = (np.cos(kap * X.astype(np.float64)) * np.sin(kap * (Y - h).astype(np.float64)) * np.cos(kap * Z.astype(np.float64))).astype(np.float32)
+    u[..., 2] = 0
+    orc.BC(u, (0, 0, 0))
+    sim.field("u0")[...] = u
+    for _ in range(warm):
+        sim.step(remeasure=False)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        sim.step(remeasure=False)
+        k += 1
+        el = time.perf_counter() - t0
+        if (steps is not None and k >= steps) or (steps is None and el >= budget_s) or k >= 400:
+            break
+    el = time.perf_counter() - t0
+    nmean = float(np.mean(sim.pois_n[2 * warm:]))
+    return {"value": n**3 * k / el, "unit": "cells*steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"3D TGV {n}^3 f32, {k} mom_step! after {warm} warm-up, OpenMP over {cores} threads, mean pois.n={nmean:.2f}",
+            "seconds": el}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=512, help="interior cells per side of the TGV box")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    import waterlily_jl_amd as w
+    from waterlily_jl_amd._lib import check
+    lib = w.lib()
+    check(lib.wl_init(local_rank))
+
+    N = args.size
+    if world > 1:
+        from waterlily_jl_amd import slab
+        return slab.bench_main(args, world, rank, local_rank)
+
+    sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+    for _ in range(args.warmup):
+        sim.mom_step_()
+    sim.sync()
+    n_warm = len(sim.pois_n)
+    check(lib.wl_prof_enable(1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.mom_step_()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = {}
+    names = {0: "gs_sweep", 1: "smooth", 2: "jacobi", 3: "conv_diff", 4: "residual", 5: "bdim", 6: "prolong_increment", 7: "coarse_levels", 8: "mom_step"}
+    for slot, nm in names.items():
+        cnt, tot = C.c_int(), C.c_double()
+        check(lib.wl_prof_read(slot, C.byref(cnt), C.byref(tot)))
+        prof[nm] = {"launches": cnt.value, "avg_ms": (tot.value / cnt.value) if cnt.value else None, "total_ms": tot.value}
+    check(lib.wl_prof_enable(0))
+    ncell = float(N) ** 3
+    pn = sim.pois_n[n_warm:]
+    # dominant kernel: the finest-level red–black colour sweep (4 launches per smooth!)
+    sweep_ms = prof["gs_sweep"]["avg_ms"]
+    ach = BYTES_GS_SWEEP * ncell / (sweep_ms * 1e-3) / 1e9
+    smooth_ms = prof["smooth"]["avg_ms"]
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    tsrc = None
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("size") == N and tj.get("kernel") == "k_gs_sweep":
+                traffic, tsrc = tj["hbm_bytes_per_launch"], tj.get("source")
+        except Exception:
+            pass
+    out = {
+        "metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": ncell * args.steps / el, "unit": "cells*steps/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false (BASELINE configs[4] domain on 1 GPU)",
+                   "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1])},
+        "roofline": {"bound": "hbm", "kernel": "k_gs_sweep<3> (finest-level red-black colour sweep, src/Poisson.jl:145)",
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
+                     "bytes_per_cell": BYTES_GS_SWEEP, "avg_launch_ms": sweep_ms, "launches": prof["gs_sweep"]["launches"],
+                     "smooth_op": {"what": "GaussSeidelRB!(it=4) as one operation, 40 B/cell", "avg_ms": smooth_ms,
+                                   "achieved": BYTES_SMOOTH_OP * ncell / (smooth_ms * 1e-3) / 1e9, "frac": BYTES_SMOOTH_OP * ncell / (smooth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+        "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items()},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

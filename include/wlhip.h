@@ -159,6 +159,15 @@ int wl_sim_measure_sphere(wl_sim* s, const float* host_center, float R, float ep
 /* pressure_force(sim) for that sphere (src/Metrics.jl:116-133): Float64 accumulation, does not touch flow.f */
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* host_center, float R, double* host_out, void* stream);
 
+/* ---- measurement hooks (bench.py): HIP-event pairs recorded on the launch stream around named launches ----
+ * slots: 0 fine-level GS colour sweep (one launch), 1 fine-level smooth! (GaussSeidelRB! as a whole),
+ *        2 fine-level Jacobi!, 3 conv_diff!, 4 fine-level residual!+norms, 5 BDIM!, 6 fine-level prolongate+increment,
+ *        7 coarse levels (everything below level 1 of a V-cycle), 8 mom_step! as a whole                         */
+enum { WL_PROF_GS_SWEEP = 0, WL_PROF_SMOOTH = 1, WL_PROF_JACOBI = 2, WL_PROF_CONVDIFF = 3, WL_PROF_RESIDUAL = 4,
+       WL_PROF_BDIM = 5, WL_PROF_PROLONG = 6, WL_PROF_COARSE = 7, WL_PROF_STEP = 8, WL_PROF_NSLOTS = 9 };
+int wl_prof_enable(int on);                                     /* also resets all slots */
+int wl_prof_read(int slot, int* host_count, double* host_total_ms);   /* synchronises the device */
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output (kernel stats + FETCH_SIZE/WRITE_SIZE PMC passes) into small committed files.
+gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts wide coalesced reads at 1/2 -> both the raw and the
+doubled figure are reported; WRITE_SIZE is exact for streaming stores. Units of both counters: KiB."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, tag, size = sys.argv[1], sys.argv[2], int(sys.argv[3])
+root = os.path.dirname(os.path.abspath(__file__))
+
+
+def find(pattern):
+    fs = glob.glob(os.path.join(out, pattern), recursive=True)
+    return fs[0] if fs else None
+
+
+summary = {"tag": tag, "size": size}
+st = find("trace/**/*kernel_stats.csv")
+if st:
+    rows = list(csv.DictReader(open(st)))
+    keep = []
+    for r in rows:
+        keep.append({k: r[k] for k in r if k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
+    summary["kernel_stats"] = keep
+    with open(os.path.join(root, f"{tag}_kernel_stats_{size}.csv"), "w") as f:
+        wri = csv.DictWriter(f, fieldnames=list(keep[0].keys()))
+        wri.writeheader()
+        wri.writerows(keep)
+
+
+def pmc(dirname, counter):
+    f = find(f"{dirname}/**/*counter_collection.csv")
+    if not f:
+        return {}
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        if r.get("Counter_Name") != counter:
+            continue
+        key = f'{r["Kernel_Name"]} @grid={r["Grid_Size"]}'     # one entry per (kernel, launch size) = per multigrid level
+        acc[key][0] += float(r["Counter_Value"])
+        acc[key][1] += 1
+    return {k: {"sum": v[0], "launches": v[1], "per_launch": v[0] / v[1]} for k, v in acc.items()}
+
+
+fe, wr = pmc("pmc_fetch", "FETCH_SIZE"), pmc("pmc_write", "WRITE_SIZE")
+traffic = {}
+for k in sorted(set(fe) | set(wr)):
+    f_kib = fe.get(k, {}).get("per_launch", 0.0)
+    w_kib = wr.get(k, {}).get("per_launch", 0.0)
+    traffic[k] = {"launches": fe.get(k, wr.get(k))["launches"], "fetch_KiB_raw": f_kib, "write_KiB": w_kib,
+                  "hbm_bytes_raw": (f_kib + w_kib) * 1024, "hbm_bytes_fetch_x2": (2 * f_kib + w_kib) * 1024}
+summary["traffic_per_launch"] = traffic
+json.dump(summary, open(os.path.join(root, f"{tag}_summary_{size}.json"), "w"), indent=1)
+# the figure bench.py reports as roofline.traffic for the dominant kernel
+best = None
+for k, v in traffic.items():
+    if "k_gs_sweep" in k and (best is None or v["hbm_bytes_raw"] > traffic[best]["hbm_bytes_raw"]):
+        best = k
+for k, v in traffic.items():
+    if k == best:
+        json.dump({"size": size, "kernel": "k_gs_sweep", "hbm_bytes_per_launch": v["hbm_bytes_fetch_x2"], "raw_bytes_per_launch": v["hbm_bytes_raw"],
+                   "source": f"profiles/{tag}_summary_{size}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per gfx950 note)"},
+                  open(os.path.join(root, "traffic_latest.json"), "w"), indent=1)
+ncell = float(size) ** 3
+for k, v in sorted(traffic.items(), key=lambda kv: -kv[1]["hbm_bytes_raw"] * kv[1]["launches"])[:24]:
+    print(f'{k[:110]:110s} n={v["launches"]:4d} raw {v["hbm_bytes_raw"]/ncell:7.2f} B/cell  fetchx2 {v["hbm_bytes_fetch_x2"]/ncell:7.2f} B/cell')

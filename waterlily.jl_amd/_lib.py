@@ -85,6 +85,8 @@ SIGNATURES = {
     "wl_sim_phase": (i32, [P, i32, P]),
     "wl_sim_apply_ic": (i32, [P, i32, P]),
     "wl_sim_measure_sphere": (i32, [P, C.POINTER(f32), f32, f32, P]),
+    "wl_prof_enable": (i32, [i32]),
+    "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),
     "wl_sim_pressure_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),
 }
 

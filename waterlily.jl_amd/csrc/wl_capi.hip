@@ -23,6 +23,18 @@ int wl_ctx_ensure() {
   return 0;
 }
 
+WlProf& wl_prof() { static WlProf p; return p; }
+ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active(false), idx(0) {
+  WlProf& p = wl_prof();
+  if (!p.on || id < 0) return;
+  WlProf::Slot& sl = p.slot[id];
+  if (sl.used >= 16384) return;
+  if (sl.used >= sl.a.size()) { hipEvent_t ea, eb; if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return; sl.a.push_back(ea); sl.b.push_back(eb); }
+  idx = sl.used++; active = true;
+  (void)hipEventRecord(sl.a[idx], s);
+}
+ProfScope::~ProfScope() { if (active) (void)hipEventRecord(wl_prof().slot[id].b[idx], s); }
+
 // ================================================================================================
 // MultiLevelPoisson handle
 // ================================================================================================
@@ -89,22 +101,33 @@ int wl_mg::update(hipStream_t s) {                                              
 // GaussSeidelRB!(p;it,ω)                                                                 src/Poisson.jl:141-148
 int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
   Level& p = lv[(size_t)l];
+  ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
   WL_TRY(wl::gs_init(p.eps, p.r, p.iD, p.x_, s));
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));
-  for (int k0 = 1; k0 <= it; k0++) WL_TRY(wl::gs_sweep(p.eps, p.r, p.L, p.iD, p.x_, k0, s));
+  for (int k0 = 1; k0 <= it; k0++) {
+    ProfScope pk(l == 0 ? WL_PROF_GS_SWEEP : -1, s);
+    WL_TRY(wl::gs_sweep(p.eps, p.r, p.L, p.iD, p.x_, k0, s));
+  }
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));                                      // perBC!(ϵ) inside increment! :101
   return wl::increment(p.r, p.x, p.eps, p.L, p.D, p.x_, w, s);
 }
 int wl_mg::vcycle(int l, float w, hipStream_t s) {                                        // Vcycle! :88-101
   Level& fine = lv[(size_t)l]; Level& coarse = lv[(size_t)l + 1];
   // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
-  WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
-  WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
-  WL_TRY(wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, 1.f, s));
-  WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
-  WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
-  if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s));
-  WL_TRY(smooth(l + 1, 4, w, s));
+  {
+    ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
+    WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
+    WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+    WL_TRY(wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, 1.f, s));
+  }
+  {
+    ProfScope pc(l == 0 ? WL_PROF_COARSE : -1, s);   // everything below the finest level
+    WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
+    WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
+    if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s));
+    WL_TRY(smooth(l + 1, 4, w, s));
+  }
+  ProfScope pp(l == 0 ? WL_PROF_PROLONG : -1, s);
   if (perdir) {
     WL_TRY(wl::prolongate(fine.eps, fine.x_, coarse.x, coarse.x_, s));
     WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
@@ -116,9 +139,12 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
   Level& p = lv[0];
   const double r1tol = (tol / 10.0) * (double)wl_ninside_global(p.g);                     // l1n_tol  src/Poisson.jl:194
   const double rinftol = tol;
-  WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                        // residual!: perBC!(x) :93
-  WL_TRY(wl::residual(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));
-  WL_TRY(wl::norms_dev(p.r, p.x_, ws, 1, 0, s));                                          // r₁ -> res_d[1], r∞ -> res_f[0]
+  {
+    ProfScope pr(WL_PROF_RESIDUAL, s);
+    WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                      // residual!: perBC!(x) :93
+    WL_TRY(wl::residual(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));
+    WL_TRY(wl::norms_dev(p.r, p.x_, ws, 1, 0, s));                                        // r₁ -> res_d[1], r∞ -> res_f[0]
+  }
   double hd[3]; float hf[2];
   float w = 1.f;
   // r₁ of the initial residual is only needed for the ω rule after the first V-cycle: fetch it lazily with the first iteration's norms
@@ -150,6 +176,23 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
 extern "C" {
 
 int wl_version(void) { return 100; }
+int wl_prof_enable(int on) {
+  WlProf& p = wl_prof();
+  WL_HIP(hipDeviceSynchronize());
+  for (int q = 0; q < WL_PROF_NSLOTS; q++) p.slot[q].used = 0;
+  p.on = on != 0;
+  return 0;
+}
+int wl_prof_read(int slot, int* count, double* total_ms) {
+  WL_CHECK(slot >= 0 && slot < WL_PROF_NSLOTS, "bad profiling slot");
+  WL_HIP(hipDeviceSynchronize());
+  WlProf::Slot& sl = wl_prof().slot[slot];
+  double tot = 0.0;
+  for (size_t q = 0; q < sl.used; q++) { float ms = 0.f; WL_HIP(hipEventElapsedTime(&ms, sl.a[q], sl.b[q])); tot += (double)ms; }
+  if (count) *count = (int)sl.used;
+  if (total_ms) *total_ms = tot;
+  return 0;
+}
 const char* wl_last_error_string(void) { return g_err.c_str(); }
 int wl_init(int device) {
   int n = 0;

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/wlhip.h"
 
@@ -55,10 +56,33 @@ static inline long wl_ncell(const wl_grid& g) { return (long)g.nx * g.ny * g.nz;
 static inline long wl_ninside_local(const wl_grid& g) { return (long)(g.nx - 2) * (g.ny - 2) * (g.D == 3 ? (g.k1 - g.k0) : 1); }
 static inline long wl_ninside_global(const wl_grid& g) { return (long)(g.nx - 2) * (g.ny - 2) * (g.D == 3 ? (g.gnz - 2) : 1); }
 
-// launch geometry: linear over an x-y plane (perfectly coalesced, ghosts masked), one z plane per blockIdx.y
-static inline dim3 wl_plane_grid(const GridX& g, int nplanes) { return dim3((unsigned)((g.sz + WL_BLOCK - 1) / WL_BLOCK), (unsigned)nplanes, 1); }
+// Launch geometry: 1-D grid; threads run linearly over an x-y plane (perfectly coalesced, ghosts masked).
+// XCD-aware block->tile map: the 8 XCDs of MI355X have private L2s and workgroups are dealt to them
+// round-robin by linear block id (b and b+8 share an XCD).  Hardware block h therefore takes strip q = h%8 of
+// the plane (a contiguous 1/8 of its rows) and walks that strip plane by plane, so the ±y and ±z stencil
+// neighbours of a cell are fetched by the SAME XCD's L2 instead of being re-fetched by up to three of them.
+static inline int wl_strip_blocks(const GridX& g) { const long nbx = (g.sz + WL_BLOCK - 1) / WL_BLOCK; return (int)((nbx + 7) >> 3); }
+static inline dim3 wl_plane_grid(const GridX& g, int nplanes) { return dim3((unsigned)(8L * wl_strip_blocks(g) * nplanes), 1, 1); }
+// plane-slot count for grid-stride reduction kernels: keeps the number of per-block partials <= WL_REDPART
+#define WL_REDPART 8192
+static inline int wl_red_slots(const GridX& g, int nplanes) { long by = WL_REDPART / (8L * wl_strip_blocks(g)); if (by < 1) by = 1; return (int)(by < nplanes ? by : nplanes); }
 
 #ifdef __HIPCC__
+// block -> (flattened in-plane index m of this thread, plane slot p); false when the block lies beyond the plane
+__device__ __forceinline__ bool wl_tile(const GridX& g, long& m, int& p) {
+  const unsigned h = blockIdx.x;
+  const unsigned q = h & 7u, s = h >> 3;
+  const long nbx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
+  const unsigned per = (unsigned)((nbx + 7) >> 3);
+  p = (int)(s / per);
+  const long bx = (long)q * per + (s - (unsigned)p * per);
+  m = bx * WL_BLOCK + threadIdx.x;
+  return bx < nbx;
+}
+__device__ __forceinline__ int wl_nslots(const GridX& g) {   // number of plane slots of this launch
+  const long nbx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
+  return (int)(gridDim.x / (8u * (unsigned)((nbx + 7) >> 3)));
+}
 // ---- wave / block reductions (wave64 shuffles, then LDS across the 4 waves of a 256-thread block) ----
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -120,6 +144,19 @@ struct WlCtx {
 };
 WlCtx& wl_ctx();
 int wl_ctx_ensure();
+
+// ---- measurement hooks: event pairs on the launch stream (see wlhip.h WL_PROF_*) ----------------------
+struct WlProf {
+  bool on = false;
+  struct Slot { std::vector<hipEvent_t> a, b; size_t used = 0; };
+  Slot slot[WL_PROF_NSLOTS];
+};
+WlProf& wl_prof();
+struct ProfScope {   // RAII: records start at construction and stop at destruction when profiling is enabled
+  int id; hipStream_t s; bool active; size_t idx;
+  ProfScope(int id_, hipStream_t s_);
+  ~ProfScope();
+};
 
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {

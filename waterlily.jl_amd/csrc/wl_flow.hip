@@ -110,10 +110,10 @@ __device__ __forceinline__ float flux_upperR(const float* __restrict__ f, const 
 //   contributing iff I_b ∈ 2..Ng_b−1 and every other I_c ∈ 2..Ng_c (upper ghost INCLUDED, as inside_u does).
 template <int D, int SCH>
 __global__ void k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float* __restrict__ Phi, float nu, unsigned per, int kfirst) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const int k = (D == 3) ? kfirst + (int)blockIdx.y : 0;
+  const int k = (D == 3) ? kfirst + (int)pz : 0;
   const long o = m + (long)k * g.sz;
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2};    // Julia (global) indices
   const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
@@ -174,10 +174,10 @@ __global__ void k_bdim_f(GridX g, float* __restrict__ f, const float* __restrict
 template <int D>
 __global__ void k_bdim_u(GridX g, float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ V, const float* __restrict__ mu0, const float* __restrict__ mu1,
                          float pre, float post, int scale_after) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   const long st[3] = {1, g.sy, g.sz};
   for (int a = 0; a < D; a++) {
     const long oa = (long)a * g.cs + o;
@@ -195,10 +195,10 @@ __global__ void k_bdim_u(GridX g, float* __restrict__ u, const float* __restrict
 template <int D>
 __global__ void k_bdim_nobody(GridX g, float* __restrict__ u, const float* __restrict__ u0, float* __restrict__ f, const float* __restrict__ mu0, float dt, float pre, float post,
                               int scale_after) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const int k = (int)blockIdx.y;
+  const int k = (int)pz;
   const long o = m + (long)k * g.sz;
   bool in = interior_ij(g, i, j);
   if (D == 3) in = in && k >= g.k0 && k < g.k1;
@@ -216,20 +216,20 @@ __global__ void k_bdim_nobody(GridX g, float* __restrict__ u, const float* __res
 }
 template <int D>
 __global__ void k_scale_u(GridX g, float* __restrict__ u, float sc) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   for (int a = 0; a < D; a++) u[(long)a * g.cs + o] *= sc;
 }
 
 // z = div(I,u)  src/Flow.jl:13-19,225 ; optional fused x *= dt over ALL cells (x may be NULL)
 template <int D>
 __global__ void k_div(GridX g, float* __restrict__ z, float* __restrict__ x, const float* __restrict__ u, float dt) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const int k = (int)blockIdx.y;
+  const int k = (int)pz;
   const long o = m + (long)k * g.sz;
   if (x) x[o] = x[o] * dt;
   bool in = interior_ij(g, i, j);
@@ -244,10 +244,10 @@ __global__ void k_div(GridX g, float* __restrict__ z, float* __restrict__ x, con
 // u[I,i] -= L[I,i]*(x[I]-x[I-δᵢ])   src/Flow.jl:227-229
 template <int D>
 __global__ void k_project(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   const float xc = x[o];
   u[o] -= L[o] * (xc - x[o - 1]);
   u[g.cs + o] -= L[g.cs + o] * (xc - x[o - g.sy]);
@@ -256,12 +256,13 @@ __global__ void k_project(GridX g, float* __restrict__ u, const float* __restric
 // CFL: σ = flux_out on the interior; block max over ALL cells of σ (ghost planes keep stale Φ — quirk Q1)  src/Flow.jl:234-244
 template <int D>
 __global__ void k_cfl(GridX g, const float* __restrict__ u, float* __restrict__ sigma, float* __restrict__ pmax, int kfirst, int klast) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   float mx = -INFINITY;
+  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j)) {
     const bool inij = interior_ij(g, i, j);
-    for (int k = kfirst + blockIdx.y; k < klast; k += gridDim.y) {
+    for (int k = kfirst + pz; k < klast; k += nsl) {
       const long o = m + (long)k * g.sz;
       bool in = inij;
       if (D == 3) in = in && k >= g.k0 && k < g.k1;
@@ -277,7 +278,7 @@ __global__ void k_cfl(GridX g, const float* __restrict__ u, float* __restrict__ 
     }
   }
   mx = block_max(mx);
-  if (threadIdx.x == 0) pmax[(long)blockIdx.y * gridDim.x + blockIdx.x] = mx;
+  if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
 }
 
 // BC!(a,U,saveexit,perdir) for tuple U — all faces and components in ONE launch.   src/core.jl:200-219
@@ -296,7 +297,7 @@ __device__ __forceinline__ bool bc_touched(const int* I, const int* N, int a, in
 }
 template <int D>
 __global__ void k_bc_vec(GridX g, float* __restrict__ a_, float U0, float U1, float U2, int saveexit, unsigned per, int zwalls) {
-  // blockIdx.y = plane id: dir d = id/3, which = id%3 -> Julia index {1,2,N_d}
+  // pz = plane id: dir d = id/3, which = id%3 -> Julia index {1,2,N_d}
   const int pid = blockIdx.y, d = pid / 3, which = pid % 3;
   const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
   const float U[3] = {U0, U1, U2};
@@ -367,7 +368,7 @@ __global__ void k_bc_per_scalar(GridX g, float* __restrict__ a_, unsigned per) {
   a_[o] = a_[os];
 }
 
-inline unsigned grid1d(size_t n) { size_t b = (n + WL_BLOCK - 1) / WL_BLOCK; if (b > 8192) b = 8192; if (b < 1) b = 1; return (unsigned)b; }
+inline unsigned grid1d(size_t n) { size_t b = (n + WL_BLOCK - 1) / WL_BLOCK; if (b > 4096) b = 4096; if (b < 1) b = 1; return (unsigned)b; }
 }  // namespace
 
 #define DSEL(D, KERN, ...)                                                           \
@@ -472,11 +473,9 @@ int project(float* u, const float* L, const float* x, const GridX& g, hipStream_
 int cfl_dev(const float* u, float* sigma, const GridX& g, const RedWs& ws, int slot_f, hipStream_t s) {
   int kfirst = 0, klast = 1;
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
-  const long bx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
-  long by = WL_MAXPART / bx; if (by < 1) by = 1; if (by > klast - kfirst) by = klast - kfirst;
-  dim3 grid((unsigned)bx, (unsigned)by, 1);
+  dim3 grid = wl_plane_grid(g, wl_red_slots(g, klast - kfirst));
   DSEL(g.D, k_cfl, grid, dim3(WL_BLOCK), 0, s, g, u, sigma, ws.pm, kfirst, klast);
-  hipLaunchKernelGGL(k_fin_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)(grid.x * grid.y), ws.res_f + slot_f);
+  hipLaunchKernelGGL(k_fin_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 }  // namespace wl

@@ -1,6 +1,6 @@
 // Poisson / multigrid leaf kernels for gfx950.  Reference semantics: /root/reference/src/Poisson.jl,
 // src/MultiLevelPoisson.jl (file:line per kernel).  All kernels: one thread per cell, linear over an
-// x-y plane (coalesced, ghosts masked), blockIdx.y walks z planes.  Arithmetic order follows the
+// x-y plane (coalesced, ghosts masked), pz walks z planes.  Arithmetic order follows the
 // reference statement by statement (compiled with -ffp-contract=off) so that element-wise results
 // are bit-identical to the CPU restatement; only reductions differ in association order.
 #include "wl_common.hpp"
@@ -28,10 +28,10 @@ __device__ __forceinline__ float Ax(const GridX& g, long o, const float* __restr
 // set_diag!   src/Poisson.jl:43-55
 template <int D>
 __global__ void k_set_diag(GridX g, float* __restrict__ Dg, float* __restrict__ iD, const float* __restrict__ L) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   float s = 0.f;
   s -= (L[o] + L[o + 1]);
   s -= (L[g.cs + o] + L[g.cs + o + g.sy]);
@@ -43,10 +43,10 @@ __global__ void k_set_diag(GridX g, float* __restrict__ Dg, float* __restrict__ 
 // mult!   src/Poisson.jl:63-69 (interior only; caller zero-fills z first)
 template <int D>
 __global__ void k_mult(GridX g, float* __restrict__ z, const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ x) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   z[o] = Ax<D>(g, o, L, Dg, x);
 }
 
@@ -54,11 +54,12 @@ __global__ void k_mult(GridX g, float* __restrict__ z, const float* __restrict__
 template <int D>
 __global__ void k_residual(GridX g, float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ z, const float* __restrict__ L,
                            const float* __restrict__ Dg, const float* __restrict__ iD, double* __restrict__ part) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   double acc = 0.0;
+  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
-    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) {
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) {
       const long o = m + (long)k * g.sz;
       const float v = (iD[o] == 0.f) ? 0.f : z[o] - Ax<D>(g, o, L, Dg, x);
       r[o] = v;
@@ -66,7 +67,7 @@ __global__ void k_residual(GridX g, float* __restrict__ r, const float* __restri
     }
   }
   acc = block_sum(acc);
-  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 // deterministic second stage: res_d[slot] = Σ partials
 __global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
@@ -90,49 +91,50 @@ __global__ void k_final_max(const float* __restrict__ pmax, int n, float* __rest
 }
 // s = Σr/N ; if |s| > 2eps(Float32): r -= s    src/Poisson.jl:95-97   (predicate evaluated on device: no host sync)
 __global__ void k_mean_shift(GridX g, float* __restrict__ r, const double* __restrict__ sum, double n_inside) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   // Julia: sum(p.r) is Float32 (pairwise); s = that / length(inside).  We round the double sum to Float32 first.
   const float s = (float)(*sum) / (float)n_inside;
   if (fabsf(s) <= 2.f * 1.1920929e-7f) return;
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   r[o] = r[o] - s;
 }
 // L₁ = Σ|r|, L∞ = max|r| over the interior (ghosts of r are identically zero)   src/Poisson.jl:190-191
 __global__ void k_norms(GridX g, const float* __restrict__ r, double* __restrict__ part, float* __restrict__ pmax) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   double acc = 0.0; float mx = 0.f;
+  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
-    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) {
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) {
       const float v = fabsf(r[m + (long)k * g.sz]);
       acc += (double)v; mx = fmaxf(mx, v);
     }
   }
   acc = block_sum(acc);
   mx = block_max(mx);
-  if (threadIdx.x == 0) { const long b = (long)blockIdx.y * gridDim.x + blockIdx.x; part[b] = acc; pmax[b] = mx; }
+  if (threadIdx.x == 0) { part[blockIdx.x] = acc; pmax[blockIdx.x] = mx; }
 }
 
 // increment!  r -= ω A ϵ ; x += ω ϵ      src/Poisson.jl:100-104
 template <int D>
 __global__ void k_increment(GridX g, float* __restrict__ r, float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ L,
                             const float* __restrict__ Dg, float w) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   r[o] = r[o] - w * Ax<D>(g, o, L, Dg, eps);
   x[o] = x[o] + w * eps[o];
 }
 
 // ϵ = r·iD    src/Poisson.jl:112,142
 __global__ void k_gs_init(GridX g, float* __restrict__ eps, const float* __restrict__ r, const float* __restrict__ iD) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const long o = m + (long)(g.k0 + blockIdx.y) * g.sz;
+  const long o = m + (long)(g.k0 + pz) * g.sz;
   eps[o] = r[o] * iD[o];
 }
 
@@ -142,10 +144,10 @@ __global__ void k_gs_init(GridX g, float* __restrict__ eps, const float* __restr
 // dimension, so when that extent (with ghosts) is odd the last interior layer is never visited (quirk Q4).
 template <int D>
 __global__ void k_gs_sweep(GridX g, float* __restrict__ eps, const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ iD, int kk0) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const int k = g.k0 + blockIdx.y;
+  const int k = g.k0 + pz;
   const int K = (D == 3) ? g.gk + k : 0;
   if (((i + j + K + D + kk0) & 1) == 0) return;
   // Q4: last dimension index (1-based) must be <= 2*(Ng÷2)-1
@@ -161,10 +163,10 @@ __global__ void k_gs_sweep(GridX g, float* __restrict__ eps, const float* __rest
 // restrict!  a[I] = Σ_{J∈up(I,c)} b[J]   src/MultiLevelPoisson.jl:6,13-19,49  (children summed x fastest, like CartesianIndices)
 template <int D>
 __global__ void k_restrict(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(gc, m, pz);
   if (!cell_ij(gc, m, i, j) || !interior_ij(gc, i, j)) return;
-  const int k = gc.k0 + blockIdx.y;
+  const int k = gc.k0 + pz;
   // 0-based: coarse i (>=1) has fine children 2i-1, 2i  (Julia: 2I-2 : 2I-1)
   const int fi = cx ? 2 * i - 1 : i, fj = cy ? 2 * j - 1 : j;
   int fk = 0;
@@ -186,20 +188,20 @@ __device__ __forceinline__ long down_off(const GridX& gf, const GridX& gc, int i
 }
 template <int D>
 __global__ void k_prolongate(GridX gf, GridX gc, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(gf, m, pz);
   if (!cell_ij(gf, m, i, j) || !interior_ij(gf, i, j)) return;
-  const int k = gf.k0 + blockIdx.y;
+  const int k = gf.k0 + pz;
   a[m + (long)k * gf.sz] = b[down_off<D>(gf, gc, i, j, k, cx, cy, cz)];
 }
 // prolongate! + increment! fused (Vcycle! :99-100): ϵ_f = x_c[down(I)] on the interior, ghost ϵ_f read from memory
 template <int D>
 __global__ void k_prolong_increment(GridX gf, GridX gc, float* __restrict__ r, float* __restrict__ x, float* __restrict__ eps, const float* __restrict__ xc,
                                     const float* __restrict__ L, const float* __restrict__ Dg, int cx, int cy, int cz, float w, int write_eps) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(gf, m, pz);
   if (!cell_ij(gf, m, i, j) || !interior_ij(gf, i, j)) return;
-  const int k = gf.k0 + blockIdx.y;
+  const int k = gf.k0 + pz;
   const long o = m + (long)k * gf.sz;
   auto E = [&](int ii, int jj, int kk, long oo) -> float {
     bool in = ii >= 1 && ii <= gf.nx - 2 && jj >= 1 && jj <= gf.ny - 2;
@@ -218,10 +220,10 @@ __global__ void k_prolong_increment(GridX gf, GridX gc, float* __restrict__ r, f
 // restrictL!  a[I,i] = restrictL(I,i,b,c)   src/MultiLevelPoisson.jl:9-11,20-26,45  (BC!(a,0) applied afterwards by bc_vec)
 template <int D>
 __global__ void k_restrictL(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(gc, m, pz);
   if (!cell_ij(gc, m, i, j) || !interior_ij(gc, i, j)) return;
-  const int k = gc.k0 + blockIdx.y;
+  const int k = gc.k0 + pz;
   const int c[3] = {cx, cy, (D == 3) ? cz : 0};
   int f0[3] = {cx ? 2 * i - 1 : i, cy ? 2 * j - 1 : j, 0};
   if (D == 3) { const int K = gc.gk + k; f0[2] = (cz ? 2 * K - 1 : K) - gf.gk; }
@@ -237,11 +239,6 @@ __global__ void k_restrictL(GridX gc, GridX gf, float* __restrict__ a, const flo
   }
 }
 
-inline int red_planes(const GridX& g, int nplanes) {  // cap total blocks at WL_MAXPART
-  const long bx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
-  long by = WL_MAXPART / bx; if (by < 1) by = 1;
-  return (int)(by < nplanes ? by : nplanes);
-}
 inline void mask_of(const GridX& fine, const GridX& coarse, int& cx, int& cy, int& cz) {
   cx = coarse.nx < fine.nx; cy = coarse.ny < fine.ny; cz = (fine.D == 3) ? (coarse.gnz < fine.gnz) : 0;
 }
@@ -261,19 +258,18 @@ int mult(float* z, const float* L, const float* Dg, const float* x, const GridX&
   WL_LAUNCH_CHECK(); return 0;
 }
 int residual(float* r, const float* x, const float* z, const float* L, const float* Dg, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s) {
-  const int np = g.k1 - g.k0, by = red_planes(g, np);
-  dim3 grid((unsigned)((g.sz + WL_BLOCK - 1) / WL_BLOCK), (unsigned)by, 1);
+  const int np = g.k1 - g.k0;
+  dim3 grid = wl_plane_grid(g, wl_red_slots(g, np));
   DSEL(g.D, k_residual, grid, dim3(WL_BLOCK), 0, s, g, r, x, z, L, Dg, iD, ws.pa);
   WL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)(grid.x * grid.y), ws.res_d + 0);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
   hipLaunchKernelGGL(k_mean_shift, wl_plane_grid(g, np), dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}));
   WL_LAUNCH_CHECK(); return 0;
 }
 int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
-  const int np = g.k1 - g.k0, by = red_planes(g, np);
-  dim3 grid((unsigned)((g.sz + WL_BLOCK - 1) / WL_BLOCK), (unsigned)by, 1);
+  dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.k1 - g.k0));
   hipLaunchKernelGGL(k_norms, grid, dim3(WL_BLOCK), 0, s, g, r, ws.pa, ws.pm);
-  hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)(grid.x * grid.y), ws.res_d + slot_d, ws.res_f + slot_f);
+  hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)grid.x, ws.res_d + slot_d, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 int increment(float* r, float* x, const float* eps, const float* L, const float* Dg, const GridX& g, float w, hipStream_t s) {

@@ -21,10 +21,10 @@ __device__ __forceinline__ bool interior_ij(const GridX& g, int i, int j) { retu
 // kind 1: wall-bounded TGV κ=π/N ; kind 2: periodic TGV κ=2π/N  
 template <int D>
 __global__ void k_apply_tgv(GridX g, float* __restrict__ u, float kx, float ky, float kz) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const int k = blockIdx.y;
+  const int k = pz;
   const long o = m + (long)k * g.sz;
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
   for (int a = 0; a < D; a++) {
@@ -40,10 +40,10 @@ __global__ void k_apply_tgv(GridX g, float* __restrict__ u, float kx, float ky, 
 }
 template <int D>
 __global__ void k_apply_const(GridX g, float* __restrict__ u, float U0, float U1, float U2) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const long o = m + (long)blockIdx.y * g.sz;
+  const long o = m + (long)pz * g.sz;
   u[o] = U0; u[g.cs + o] = U1; if (D == 3) u[2 * g.cs + o] = U2;
 }
 
@@ -72,10 +72,10 @@ __device__ __forceinline__ void sphere_measure(const float* x, const float* c, f
 // measure!(flow,body;ϵ) for the sphere: fills σ(sdf), μ₀, μ₁, V(=0) on the interior   src/Body.jl:28-48
 template <int D>
 __global__ void k_measure_sphere(GridX g, float* __restrict__ sig, float* __restrict__ mu0, float* __restrict__ mu1, float c0, float c1, float c2, float R, float e) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
-  const int k = g.k0 + blockIdx.y;
+  const int k = g.k0 + pz;
   const long o = m + (long)k * g.sz;
   const float c[3] = {c0, c1, c2};
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
@@ -99,12 +99,13 @@ __global__ void k_measure_sphere(GridX g, float* __restrict__ sig, float* __rest
 // pressure_force: Σ_inside p[I]·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:116-133
 template <int D>
 __global__ void k_pforce_sphere(GridX g, const float* __restrict__ p, float c0, float c1, float c2, float R, double* __restrict__ part) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   double acc[3] = {0, 0, 0};
   const float c[3] = {c0, c1, c2};
+  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
-    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) {
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) {
       const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
       float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
       float d, n[3]; sphere_measure<D>(x, c, R, 1.f, d, n);
@@ -113,7 +114,7 @@ __global__ void k_pforce_sphere(GridX g, const float* __restrict__ p, float c0, 
       for (int a = 0; a < D; a++) acc[a] += (double)(pv * (n[a] * kk));
     }
   }
-  const long b = (long)blockIdx.y * gridDim.x + blockIdx.x, nb = (long)gridDim.x * gridDim.y;
+  const long b = blockIdx.x, nb = gridDim.x;
   for (int a = 0; a < 3; a++) { const double v = block_sum(acc[a]); if (threadIdx.x == 0) part[a * nb + b] = v; __syncthreads(); }
 }
 __global__ void k_fin3(const double* __restrict__ part, int nb, double* __restrict__ out) {
@@ -124,13 +125,14 @@ __global__ void k_fin3(const double* __restrict__ part, int nb, double* __restri
 }
 template <int D>
 __global__ void k_l2_inside(GridX g, const float* __restrict__ a, double* __restrict__ part) {
-  int i, j;
-  const long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
   double acc = 0.0;
+  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j) && interior_ij(g, i, j))
-    for (int k = g.k0 + blockIdx.y; k < g.k1; k += gridDim.y) { const double v = (double)a[m + (long)k * g.sz]; acc += v * v; }
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) { const double v = (double)a[m + (long)k * g.sz]; acc += v * v; }
   acc = block_sum(acc);
-  if (threadIdx.x == 0) part[(long)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 __global__ void k_fin1(const double* __restrict__ part, int n, double* __restrict__ out) {
   double a = 0.0; for (int q = threadIdx.x; q < n; q += WL_BLOCK) a += part[q];
@@ -188,15 +190,15 @@ struct wl_sim {
   int bc_u(hipStream_t s) { return wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s); }
   int exit_bc(hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
-    WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s));
-    WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
+    { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
+    { ProfScope pb(WL_PROF_BDIM, s); WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 0.f, 1.f, s)); }   // scale_u!(a,0) folded (pre=0)
     WL_TRY(bc_u(s));
     if (d.exitBC) WL_TRY(exit_bc(s));
     return 0;
   }
   int correct(hipStream_t s) {                                                           // mom_correct! :205-210
-    WL_TRY(wl::conv_diff(f, u, sigma, G, d.nu, d.perdir_mask, d.scheme, s));
-    WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
+    { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
+    { ProfScope pb(WL_PROF_BDIM, s); WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 1.f, 0.5f, s)); }  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
   int project(float w, hipStream_t s) {                                                  // mom_project! :223-232
@@ -214,6 +216,7 @@ struct wl_sim {
     return 0;
   }
   int mom_step(hipStream_t s) {                                                          // mom_step! :156-167
+    ProfScope pstep(WL_PROF_STEP, s);
     WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s));   // u⁰ .= u
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s));
@@ -252,9 +255,9 @@ int wl_L2_inside(const float* a, const wl_grid* g, double* out, void* st) {
   WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
   const GridX G = gx(*g); hipStream_t s = wl_stream(st);
   const RedWs ws = wl_red_ws(wl_ctx().red);
-  const long bx = (G.sz + WL_BLOCK - 1) / WL_BLOCK; long by = WL_MAXPART / bx; if (by < 1) by = 1; if (by > G.k1 - G.k0) by = G.k1 - G.k0;
-  DSEL(G.D, k_l2_inside, dim3((unsigned)bx, (unsigned)by), dim3(WL_BLOCK), 0, s, G, a, ws.pa);
-  hipLaunchKernelGGL(k_fin1, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)(bx * by), ws.res_d + 0);
+  dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
+  DSEL(G.D, k_l2_inside, grid, dim3(WL_BLOCK), 0, s, G, a, ws.pa);
+  hipLaunchKernelGGL(k_fin1, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
   WL_LAUNCH_CHECK();
   return wl::read_results(ws, out, 1, nullptr, 0, s);
 }
@@ -351,10 +354,10 @@ int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* s
 }
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {
   hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
-  const long bx = (G.sz + WL_BLOCK - 1) / WL_BLOCK; long by = (WL_MAXPART / 3) / bx; if (by < 1) by = 1; if (by > G.k1 - G.k0) by = G.k1 - G.k0;
-  // partials need 3*nb doubles: pa and pb are contiguous (2*WL_MAXPART doubles)
-  DSEL(D, k_pforce_sphere, dim3((unsigned)bx, (unsigned)by), dim3(WL_BLOCK), 0, q, G, (const float*)s->p, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
-  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)(bx * by), s->mg->ws.res_d + 4);
+  dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
+  // partials need 3*grid.x doubles (<= 3*WL_REDPART): pa and pb are contiguous (2*WL_MAXPART doubles)
+  DSEL(D, k_pforce_sphere, grid, dim3(WL_BLOCK), 0, q, G, (const float*)s->p, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
+  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)grid.x, s->mg->ws.res_d + 4);
   WL_LAUNCH_CHECK();
   WlCtx& cx = wl_ctx();
   WL_HIP(hipMemcpyAsync(cx.h_d, s->mg->ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
