@@ -159,6 +159,31 @@ int wl_sim_measure_sphere(wl_sim* s, const float* host_center, float R, float ep
 /* pressure_force(sim) for that sphere (src/Metrics.jl:116-133): Float64 accumulation, does not touch flow.f */
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* host_center, float R, double* host_out, void* stream);
 
+/* ---- multi-GPU: z-slab decomposition, one process per GPU (NEW — the reference has no multi-device path,
+ * /root/reference/README.md:153-155).  A wl_comm carries the two primitives the slab path needs, stream-ordered:
+ * a nearest-neighbour plane exchange along z and an all-gather; scalars (Σr, L₁, L∞, max σ) are combined on
+ * device from an all-gather, so every rank takes identical control-flow decisions.  Two implementations:
+ *   rccl      — ncclSend/ncclRecv groups + ncclAllGather on the compute stream (RCCL over xGMI), librccl.so.1
+ *               resolved at run time so the process shares PyTorch's copy;
+ *   callbacks — host function pointers (tests: torch.distributed/gloo staging through host memory).          */
+typedef struct wl_comm wl_comm;
+typedef int (*wl_sendrecv_fn)(void* ctx, const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes, void* stream);
+typedef int (*wl_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes_each, void* stream);
+int wl_comm_rccl_unique_id(char out128[128]);
+int wl_comm_rccl_create(wl_comm** out, int rank, int size, const char uid128[128]);
+int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_sendrecv_fn sendrecv, wl_allgather_fn allgather);
+int wl_comm_destroy(wl_comm* c);
+int wl_comm_rank(const wl_comm* c);
+int wl_comm_size(const wl_comm* c);
+/* exchange `depth` z-planes of an (ncomp)-component field with both neighbours (test hook; the composites call it internally) */
+int wl_halo_exchange(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* stream);
+/* in-place all-gather of the planes [view->k0,view->k1) each rank computed of a replicated (full) array (test hook) */
+int wl_allgather_planes(wl_comm* c, float* a, const wl_grid* view, int ncomp, void* stream);
+/* slab grid of `rank` for a GLOBAL ghosted size; halo = ghost planes kept in z (2 for velocity-like fields) */
+int wl_grid_slab(wl_grid* out, int D, const int32_t* global_dims_with_ghosts, int rank, int size, int halo);
+/* Simulation on a z-slab: desc->dims are the GLOBAL interior sizes; arrays are allocated by the handle (caller pointers must be NULL) */
+int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm);
+
 /* ---- measurement hooks (bench.py): HIP-event pairs recorded on the launch stream around named launches ----
  * slots: 0 fine-level GS colour sweep (one launch), 1 fine-level smooth! (GaussSeidelRB! as a whole),
  *        2 fine-level Jacobi!, 3 conv_diff!, 4 fine-level residual!+norms, 5 BDIM!, 6 fine-level prolongate+increment,

@@ -1,0 +1,117 @@
+"""Worker for the multi-process slab tests (launched by test_slab_cpu.py / test_gpu_slab.py, one process per rank).
+mode cpu_halo : gloo + HOST buffers — exercises the library's halo/all-gather pointer arithmetic and the transport (no GPU).
+mode gpu_sim  : gloo + the one GPU of the box — P slab ranks against the single-domain FusedSimulation.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    mode = sys.argv[1]
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="nccl" if mode == "gpu_rccl1" else "gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    import waterlily_jl_amd as w
+    from waterlily_jl_amd import slab
+    from waterlily_jl_amd._lib import check, lib
+    L = lib()
+    if mode == "cpu_halo":
+        comm = slab.CallbackComm(dist, host_buffers=True)
+        gd = (10, 7, 2 + 6 * size)
+        g = slab.slab_grid(gd, rank, size, halo=2)
+        assert (g.nz, g.k0, g.k1, g.gnz) == (6 + 4, 2, 8, gd[2]) and g.gk == 1 + rank * 6 - 2
+        ncomp = 3
+        # global field f(x,y,K,c) = unique number; local slab filled on owned planes only, halos = -1
+        a = np.full((g.nx, g.ny, g.nz, ncomp), -1.0, dtype=np.float32, order="F")
+        val = lambda K, c: (np.arange(g.nx)[:, None] + 100 * np.arange(g.ny)[None, :] + 10000 * K + 1e6 * c).astype(np.float32)
+        for k in range(g.k0, g.k1):
+            for c in range(ncomp):
+                a[:, :, k, c] = val(g.gk + k, c)
+        for depth in (1, 2):
+            b = a.copy(order="F")
+            check(L.wl_halo_exchange(comm.handle, b.ctypes.data_as(C.c_void_p), C.byref(g), ncomp, depth, None))
+            for c in range(ncomp):
+                for d in range(1, depth + 1):
+                    lo, hi = g.k0 - d, g.k1 + d - 1
+                    if rank > 0:
+                        assert np.array_equal(b[:, :, lo, c], val(g.gk + lo, c)), ("lo", depth, d)
+                    else:
+                        assert np.all(b[:, :, lo, c] == -1)
+                    if rank < size - 1:
+                        assert np.array_equal(b[:, :, hi, c], val(g.gk + hi, c)), ("hi", depth, d)
+                    else:
+                        assert np.all(b[:, :, hi, c] == -1)
+                if depth == 1:   # the outer ghost plane must be untouched by a depth-1 exchange
+                    assert np.all(b[:, :, g.k0 - 2, c] == -1) and np.all(b[:, :, g.k1 + 1, c] == -1)
+            assert np.array_equal(b[:, :, g.k0:g.k1], a[:, :, g.k0:g.k1])
+        # all-gather of the planes each rank computed of a replicated array
+        nc = 3
+        from waterlily_jl_amd._lib import wl_grid
+        view = wl_grid(); view.D = 3; view.nx, view.ny = 6, 5; view.gnz = view.nz = 2 + nc * size; view.gk = 0
+        view.k0, view.k1 = 1 + rank * nc, 1 + (rank + 1) * nc
+        full = np.zeros((6, 5, view.nz, 2), dtype=np.float32, order="F")
+        for k in range(view.k0, view.k1):
+            full[:, :, k, :] = 1000 * k + rank + 1
+        check(L.wl_allgather_planes(comm.handle, full.ctypes.data_as(C.c_void_p), C.byref(view), 2, None))
+        for r in range(size):
+            for k in range(1 + r * nc, 1 + (r + 1) * nc):
+                assert np.all(full[:, :, k, :] == 1000 * k + r + 1)
+        assert np.all(full[:, :, 0, :] == 0) and np.all(full[:, :, -1, :] == 0)
+        comm.destroy()
+        print(f"rank {rank}: cpu_halo ok", flush=True)
+    elif mode == "gpu_sim":
+        torch.cuda.set_device(0)
+        dims = tuple(int(v) for v in sys.argv[2].split("x"))
+        steps = int(sys.argv[3])
+        comm = slab.CallbackComm(dist)
+        nu = dims[0] / 1600.0
+        sim = slab.SlabSimulation(comm, dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv")
+        ref = w.FusedSimulation(dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv") if rank == 0 else None
+        for s in range(steps):
+            sim.mom_step_()
+            u = sim.gather_field("u", dist)
+            p = sim.gather_field("p", dist)
+            if rank == 0:
+                ref.mom_step_()
+                ur, pr = ref.field("u"), ref.field("p")
+                du, dp = np.abs(u - ur).max(), np.abs(p - pr).max()
+                print(f"step {s}: max|du|={du:.3e} max|dp|={dp:.3e} n_slab={sim.pois_n[-2:]} n_ref={ref.pois_n[-2:]} dt={sim.dt[-1]:.6f}/{ref.dt[-1]:.6f}", flush=True)
+                assert sim.pois_n == ref.pois_n
+                assert abs(float(sim.dt[-1]) - float(ref.dt[-1])) <= 1e-6 * float(ref.dt[-1])
+                assert du < 2e-5 and dp < 2e-4, (du, dp)   # only the reductions' association order differs
+        dist.barrier()
+        del sim
+        comm.destroy()
+        print(f"rank {rank}: gpu_sim ok", flush=True)
+    elif mode == "gpu_rccl1":
+        # RCCL transport smoke test with the ranks one box offers (1): dlopen of librccl.so.1 shared with torch,
+        # unique-id broadcast, ncclCommInitRank, ncclAllGather on the stream, a whole slab step through the RCCL comm object.
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        comm = slab.RcclComm(dist, dev)
+        from waterlily_jl_amd._lib import wl_grid
+        view = wl_grid(); view.D = 3; view.nx, view.ny = 6, 5; view.gnz = view.nz = 5; view.gk = 0; view.k0, view.k1 = 1, 4
+        t = torch.arange(6 * 5 * 5, dtype=torch.float32, device=dev)
+        before = t.clone()
+        check(L.wl_allgather_planes(comm.handle, C.c_void_p(t.data_ptr()), C.byref(view), 1, None))
+        torch.cuda.synchronize()
+        assert torch.equal(t, before)
+        sim = slab.SlabSimulation(comm, (32, 32, 32), (0, 0, 0), 32, U=1, nu=0.02, ic="tgv")
+        ref = w.FusedSimulation((32, 32, 32), (0, 0, 0), 32, U=1, nu=0.02, ic="tgv")
+        sim.mom_step_(); ref.mom_step_()
+        assert np.array_equal(sim.local_field("u"), ref.field("u")) and sim.pois_n == ref.pois_n
+        del sim
+        comm.destroy()
+        print(f"rank {rank}: gpu_rccl1 ok", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

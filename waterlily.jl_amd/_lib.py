@@ -19,6 +19,8 @@ class wl_sim_desc(C.Structure):
                 ("V", C.c_void_p), ("mu0", C.c_void_p), ("mu1", C.c_void_p)]
 
 
+SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 P, G = C.c_void_p, C.POINTER(wl_grid)
 f32, f64, i32, u32, sz = C.c_float, C.c_double, C.c_int, C.c_uint, C.c_size_t
 # name -> (restype, argtypes); every symbol include/wlhip.h declares
@@ -85,6 +87,16 @@ SIGNATURES = {
     "wl_sim_phase": (i32, [P, i32, P]),
     "wl_sim_apply_ic": (i32, [P, i32, P]),
     "wl_sim_measure_sphere": (i32, [P, C.POINTER(f32), f32, f32, P]),
+    "wl_comm_rccl_unique_id": (i32, [C.c_char_p]),
+    "wl_comm_rccl_create": (i32, [C.POINTER(P), i32, i32, C.c_char_p]),
+    "wl_comm_callbacks_create": (i32, [C.POINTER(P), i32, i32, P, P, P]),
+    "wl_comm_destroy": (i32, [P]),
+    "wl_comm_rank": (i32, [P]),
+    "wl_comm_size": (i32, [P]),
+    "wl_halo_exchange": (i32, [P, P, G, i32, i32, P]),
+    "wl_allgather_planes": (i32, [P, P, G, i32, P]),
+    "wl_grid_slab": (i32, [G, i32, C.POINTER(C.c_int32), i32, i32, i32]),
+    "wl_sim_create_slab": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc), P]),
     "wl_prof_enable": (i32, [i32]),
     "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),
     "wl_sim_pressure_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),

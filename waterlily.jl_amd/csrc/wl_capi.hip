@@ -40,32 +40,41 @@ ProfScope::~ProfScope() { if (active) (void)hipEventRecord(wl_prof().slot[id].b[
 // ================================================================================================
 static inline bool divisible(int n) { return (n % 2 == 0) && n > 4; }   // src/MultiLevelPoisson.jl:52
 
-int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels) {
-  perdir = per;
+int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels, wl_comm* c) {
+  perdir = per; comm = (c && c->size > 1) ? c : nullptr;
   WL_TRY(wl_ctx_ensure());
   WL_HIP(hipMalloc(&red, wl_red_bytes()));
   ws = wl_red_ws(red);
+  const bool dist0 = comm && g0.D == 3 && g0.nz != g0.gnz;
+  if (dist0 && ((per >> 2) & 1u)) { wl_set_error("a z-periodic domain cannot be cut into z-slabs this round"); return WL_EINVAL; }
   // level 1 aliases the caller's arrays; r,ϵ,D,iD owned                                 src/Poisson.jl:32-38
-  std::vector<wl_grid> grids; grids.push_back(g0);
+  std::vector<wl_grid> grids; std::vector<char> isdist; std::vector<wl_grid> views; std::vector<char> hasview;
+  grids.push_back(g0); isdist.push_back(dist0); views.push_back(g0); hasview.push_back(0);
   while ((int)grids.size() <= maxlevels) {                                               // :70
-    const wl_grid& f = grids.back();
+    const wl_grid f = grids.back(); const bool fd = isdist.back();
     const bool cx = divisible(f.nx), cy = divisible(f.ny), cz = (f.D == 3) && divisible(f.gnz);
     if (!(cx || cy || cz)) break;                                                        // divisible(l) :54
-    wl_grid c = f;
-    if (cx) c.nx = 1 + f.nx / 2;                                                         // restrictML :36
-    if (cy) c.ny = 1 + f.ny / 2;
-    if (cz) {
-      // z-slab: interior planes must pair up inside the rank (global interior start is odd in 0-based => local count even)
+    wl_grid cgr = f; wl_grid vw = f; bool cd = fd, hv = false;
+    if (cx) cgr.nx = 1 + f.nx / 2;                                                       // restrictML :36
+    if (cy) cgr.ny = 1 + f.ny / 2;
+    const int gnz_c = cz ? 1 + f.gnz / 2 : f.gnz;
+    if (!fd) { if (f.D == 3) { cgr.gnz = gnz_c; cgr.nz = gnz_c; cgr.k0 = 1; cgr.k1 = gnz_c - 1; cgr.gk = 0; } }
+    else {
       const int nloc = f.k1 - f.k0;
-      if (f.nz != f.gnz && (nloc % 2 != 0)) break;   // distributed level cannot be coarsened further locally (caller agglomerates)
-      c.gnz = 1 + f.gnz / 2;
-      const int nl = nloc / 2;
-      c.k0 = f.k0; c.k1 = c.k0 + nl; c.nz = nl + 2 * c.k0;
-      // global index of first interior plane: fine G = gk+k0 (odd, >=1) -> coarse (G+1)/2
-      c.gk = (f.gk + f.k0 + 1) / 2 - c.k0;
-      if (f.nz == f.gnz) { c.nz = c.gnz; c.k0 = 1; c.k1 = c.nz - 1; c.gk = 0; }
+      const int nc = cz ? nloc / 2 : nloc;
+      // stay distributed while the local planes pair up and the level is still big; otherwise replicate on every rank
+      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > 32;
+      if (cz && (nloc % 2 != 0)) { wl_set_error("z-slab: local plane count must stay even until the level is replicated (use nz = P*2^k)"); return WL_EINVAL; }
+      if (keep) {
+        cgr.gnz = gnz_c; cgr.k0 = f.k0; cgr.k1 = cgr.k0 + nc; cgr.nz = nc + 2 * cgr.k0;
+        cgr.gk = (cz ? (f.gk + f.k0 + 1) / 2 : f.gk + f.k0) - cgr.k0;
+      } else {   // replicated: full array; this rank computes the planes below its own fine planes, then all-gathers
+        cd = false; hv = true;
+        cgr.gnz = gnz_c; cgr.nz = gnz_c; cgr.k0 = 1; cgr.k1 = gnz_c - 1; cgr.gk = 0;
+        vw = cgr; vw.k0 = cz ? (f.gk + f.k0 + 1) / 2 : f.gk + f.k0; vw.k1 = vw.k0 + nc;
+      }
     }
-    grids.push_back(c);
+    grids.push_back(cgr); isdist.push_back(cd); views.push_back(vw); hasview.push_back(hv);
   }
   if (grids.size() <= 2) { wl_set_error("MultiLevelPoisson requires size=a2ⁿ, where n>2"); return WL_ELEVELS; }   // :73-74
   // one slab allocation for everything the handle owns
@@ -76,24 +85,36 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
   float* p = slab;
   lv.resize(grids.size());
   for (size_t l = 0; l < grids.size(); l++) {
-    Level& v = lv[l]; v.g = grids[l]; v.x_ = gx(grids[l]);
+    Level& v = lv[l]; v.g = grids[l]; v.x_ = gx(grids[l]); v.dist = isdist[l]; v.has_view = hasview[l]; v.view = gx(views[l]);
     const size_t nc = (size_t)wl_ncell(grids[l]);
     v.r = p; p += nc; v.eps = p; p += nc; v.D = p; p += nc; v.iD = p; p += nc;
     if (l == 0) { v.x = x; v.L = L; v.z = z; }
     else { v.L = p; p += nc * (size_t)grids[l].D; v.x = p; p += nc; v.z = p; p += nc; }
   }
   hipStream_t s = 0;
-  for (size_t l = 1; l < lv.size(); l++) WL_TRY(wl::restrictL(lv[l].L, lv[l].x_, lv[l - 1].L, lv[l - 1].x_, perdir, s));    // restrictML :39
-  for (size_t l = 0; l < lv.size(); l++) WL_TRY(wl::set_diag(lv[l].D, lv[l].iD, lv[l].L, lv[l].x_, s));                  // Poisson ctor :36
+  WL_TRY(update(s));                                                                       // restrictML :39 + Poisson ctor :36
   WL_HIP(hipStreamSynchronize(s));
   return 0;
 }
 wl_mg::~wl_mg() { if (slab) (void)hipFree(slab); if (red) (void)hipFree(red); }
 
+// coarse face coefficients of level l from level l-1 (restrictL! :42-48), slab aware
+static int restrictL_level(wl_mg& m, size_t l, hipStream_t s) {
+  wl_mg::Level& c = m.lv[l]; wl_mg::Level& f = m.lv[l - 1];
+  if (c.has_view) {          // distributed parent -> replicated child: compute my planes, all-gather, then BC!(a,0) on the full array
+    const float zero[3] = {0.f, 0.f, 0.f};
+    WL_TRY(wl::restrictL(c.L, c.view, f.L, f.x_, m.perdir, s));     // (its BC pass is redone below on the complete array)
+    WL_TRY(wl::allgather_planes(m.comm, c.L, c.view, c.g.D, s));
+    return wl::bc_vec(c.L, c.x_, zero, 0, m.perdir, s);
+  }
+  WL_TRY(wl::restrictL(c.L, c.x_, f.L, f.x_, m.perdir, s));
+  return m.halo(c, c.L, c.g.D, s);
+}
 int wl_mg::update(hipStream_t s) {                                                        // update! :79-86
+  WL_TRY(halo(lv[0], lv[0].L, lv[0].g.D, s));
   WL_TRY(wl::set_diag(lv[0].D, lv[0].iD, lv[0].L, lv[0].x_, s));
   for (size_t l = 1; l < lv.size(); l++) {
-    WL_TRY(wl::restrictL(lv[l].L, lv[l].x_, lv[l - 1].L, lv[l - 1].x_, perdir, s));
+    WL_TRY(restrictL_level(*this, l, s));
     WL_TRY(wl::set_diag(lv[l].D, lv[l].iD, lv[l].L, lv[l].x_, s));
   }
   return 0;
@@ -104,9 +125,11 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
   ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
   WL_TRY(wl::gs_init(p.eps, p.r, p.iD, p.x_, s));
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));
+  WL_TRY(halo(p, p.eps, 1, s));
   for (int k0 = 1; k0 <= it; k0++) {
     ProfScope pk(l == 0 ? WL_PROF_GS_SWEEP : -1, s);
     WL_TRY(wl::gs_sweep(p.eps, p.r, p.L, p.iD, p.x_, k0, s));
+    WL_TRY(halo(p, p.eps, 1, s));                                                          // neighbour slabs need this colour before the next sweep
   }
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));                                      // perBC!(ϵ) inside increment! :101
   return wl::increment(p.r, p.x, p.eps, p.L, p.D, p.x_, w, s);
@@ -118,19 +141,25 @@ int wl_mg::vcycle(int l, float w, hipStream_t s) {                              
     ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
     WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
     WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+    WL_TRY(halo(fine, fine.eps, 1, s));
     WL_TRY(wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, 1.f, s));
   }
   {
     ProfScope pc(l == 0 ? WL_PROF_COARSE : -1, s);   // everything below the finest level
-    WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
+    if (coarse.has_view) {
+      WL_TRY(wl::restrict_(coarse.r, coarse.view, fine.r, fine.x_, s));
+      WL_TRY(wl::allgather_planes(comm, coarse.r, coarse.view, 1, s));
+    } else WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
     WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
     if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s));
     WL_TRY(smooth(l + 1, 4, w, s));
+    WL_TRY(halo(coarse, coarse.x, 1, s));                                                  // prolongation reads the coarse cells under my halo planes
   }
   ProfScope pp(l == 0 ? WL_PROF_PROLONG : -1, s);
   if (perdir) {
     WL_TRY(wl::prolongate(fine.eps, fine.x_, coarse.x, coarse.x_, s));
     WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+    WL_TRY(halo(fine, fine.eps, 1, s));
     return wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, w, s);
   }
   return wl::prolong_increment(fine.r, fine.x, fine.eps, coarse.x, fine.L, fine.D, fine.x_, coarse.x_, w, true, s);
@@ -142,12 +171,15 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
   {
     ProfScope pr(WL_PROF_RESIDUAL, s);
     WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                      // residual!: perBC!(x) :93
-    WL_TRY(wl::residual(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));
+    WL_TRY(halo(p, p.x, 1, s));
+    WL_TRY(wl::residual_part(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));               // r and the local Σr -> res_d[0]
+    WL_TRY(wl::combine_results(comm, ws, s));
+    WL_TRY(wl::mean_shift(p.r, p.x_, ws, s));
     WL_TRY(wl::norms_dev(p.r, p.x_, ws, 1, 0, s));                                        // r₁ -> res_d[1], r∞ -> res_f[0]
   }
   double hd[3]; float hf[2];
   float w = 1.f;
-  // r₁ of the initial residual is only needed for the ω rule after the first V-cycle: fetch it lazily with the first iteration's norms
+  // r₁ of the initial residual is only needed for the ω rule after the first V-cycle: fetched with the first iteration's norms
   bool have_r1 = false; float r1 = 0.f, rinf = 0.f;
   int np = 0;
   log_r1.clear(); log_rinf.clear(); log_w.clear();
@@ -155,6 +187,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     WL_TRY(vcycle(0, w, s));
     WL_TRY(smooth(0, 4, w, s));
     WL_TRY(wl::norms_dev(p.r, p.x_, ws, 2, 1, s));                                        // rnew -> res_d[2], r∞ -> res_f[1]
+    WL_TRY(wl::combine_results(comm, ws, s));                                             // (slot 0 becomes P·Σr: not used again)
     WL_TRY(wl::read_results(ws, hd, 3, hf, 2, s));
     if (!have_r1) { r1 = (float)hd[1]; log_r1.push_back(hd[1]); log_rinf.push_back(hf[0]); log_w.push_back(1.0); have_r1 = true; }
     const float rnew = (float)hd[2]; rinf = hf[1]; np++;
@@ -165,6 +198,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     if ((double)r1 < r1tol && (double)rinf < rinftol) break;
   }
   WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                        // :126
+  WL_TRY(halo(p, p.x, 1, s));                                                             // projection reads x[I-δz] across the slab face
   n.push_back((int16_t)np);
   if (host_n) *host_n = np;
   if (host_r1) *host_r1 = (double)r1;
@@ -287,7 +321,7 @@ int wl_coarsen_dims(int D, const int32_t* fine, int32_t* coarse) {
 int wl_mg_create(wl_mg** out, float* x, float* L, float* z, const wl_grid* g, unsigned per, int maxlevels) {
   WL_CHECK(out && x && L && z, "null pointer"); WL_CHECK(wl_grid_ok(g), "bad wl_grid");
   wl_mg* mg = new wl_mg();
-  int rc = mg->build(x, L, z, *g, per, maxlevels <= 0 ? 10 : maxlevels);
+  int rc = mg->build(x, L, z, *g, per, maxlevels <= 0 ? 10 : maxlevels, nullptr);
   if (rc != 0) { delete mg; *out = nullptr; return rc; }
   *out = mg; return 0;
 }

@@ -1,0 +1,24 @@
+// z-slab communication layer (see include/wlhip.h "multi-GPU").
+#pragma once
+#include "wl_common.hpp"
+
+struct wl_comm {
+  int rank = 0, size = 1;
+  void* gather = nullptr;   // device scratch for scalar all-gathers: size * 128 bytes
+  virtual ~wl_comm();
+  // lo neighbour = rank-1, hi neighbour = rank+1; pointers are NULL where there is no neighbour
+  virtual int sendrecv(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes, hipStream_t s) = 0;
+  virtual int allgather(const void* send, void* recv, size_t bytes_each, hipStream_t s) = 0;
+  virtual int group_begin() { return 0; }
+  virtual int group_end() { return 0; }
+  int ensure_scratch();
+};
+
+namespace wl {
+// exchange `depth` planes of an ncomp-component field along z with both neighbours
+int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s);
+// ws.res_d[0..7] <- Σ over ranks, ws.res_f[0..7] <- max over ranks (on device, stream ordered); no-op without comm
+int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s);
+// in-place all-gather of the owned planes [k0,k1) of a replicated (full) array whose rank blocks are contiguous
+int allgather_planes(wl_comm* c, float* a, const GridX& view, int ncomp, hipStream_t s);
+}  // namespace wl

@@ -174,6 +174,8 @@ int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per,
 int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s);
+int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s);
+int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s);
 int scale_u(float* u, const GridX& g, float sc, hipStream_t s);
 int div(float* z, const float* u, const GridX& g, hipStream_t s);
 int div_scale(float* z, float* x, const float* u, const GridX& g, float dt, hipStream_t s);   // z=div(u); x*=dt  (fused, src/Flow.jl:225)
@@ -183,6 +185,8 @@ int cfl_dev(const float* u, float* sigma, const GridX& g, const RedWs& ws, int s
 int set_diag(float* D, float* iD, const float* L, const GridX& g, hipStream_t s);
 int mult(float* z, const float* L, const float* D, const float* x, const GridX& g, hipStream_t s);
 int residual(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s);
+int residual_part(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s);
+int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s);
 // computes L₁/L∞ of r into ws.res_d[slot_d], ws.res_f[slot_f] (device) — ghosts of r are zero by construction
 int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 int increment(float* r, float* x, const float* eps, const float* L, const float* D, const GridX& g, float w, hipStream_t s);

@@ -466,6 +466,15 @@ int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, 
   }
   WL_LAUNCH_CHECK(); return 0;
 }
+int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s) {
+  const long n = g.cs * g.D;
+  hipLaunchKernelGGL(k_bdim_f, dim3(grid1d((size_t)n)), dim3(WL_BLOCK), 0, s, g, f, u0, V, dt, n);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s) {
+  DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, (post != 1.f) ? 1 : 0);
+  WL_LAUNCH_CHECK(); return 0;
+}
 int scale_u(float* u, const GridX& g, float sc, hipStream_t s) { DSEL(g.D, k_scale_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, sc); WL_LAUNCH_CHECK(); return 0; }
 int div(float* z, const float* u, const GridX& g, hipStream_t s) { DSEL(g.D, k_div, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, z, (float*)nullptr, u, 1.f); WL_LAUNCH_CHECK(); return 0; }
 int div_scale(float* z, float* x, const float* u, const GridX& g, float dt, hipStream_t s) { DSEL(g.D, k_div, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, z, x, u, dt); WL_LAUNCH_CHECK(); return 0; }

@@ -2,13 +2,17 @@
 #pragma once
 #include <vector>
 
-#include "wl_common.hpp"
+#include "wl_comm.hpp"
 
 struct wl_mg {
   struct Level {            // one `Poisson` (src/Poisson.jl:22-39)
     wl_grid g; GridX x_;
     float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
+    bool dist = false;       // z-slab distributed level (halo exchanges) vs replicated on every rank
+    GridX view;              // replicated level fed by a distributed parent: the planes of the full array this rank computes
+    bool has_view = false;
   };
+  wl_comm* comm = nullptr;   // not owned
   std::vector<Level> lv;
   std::vector<int16_t> n;   // pois.n :66
   unsigned perdir = 0;
@@ -17,7 +21,8 @@ struct wl_mg {
   RedWs ws;
   std::vector<double> log_r1, log_rinf, log_w;
 
-  int build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels);
+  int build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels, wl_comm* c = nullptr);
+  int halo(Level& v, float* a, int ncomp, hipStream_t s) { return v.dist ? wl::halo(comm, a, v.x_, ncomp, 1, s) : 0; }
   ~wl_mg();
   int update(hipStream_t s);
   int smooth(int l, int it, float w, hipStream_t s);

@@ -257,14 +257,21 @@ int mult(float* z, const float* L, const float* Dg, const float* x, const GridX&
   DSEL(g.D, k_mult, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, z, L, Dg, x);
   WL_LAUNCH_CHECK(); return 0;
 }
-int residual(float* r, const float* x, const float* z, const float* L, const float* Dg, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s) {
+// residual!: r and the LOCAL Σr (-> ws.res_d[0]); the global mean shift follows once Σr is combined over ranks
+int residual_part(float* r, const float* x, const float* z, const float* L, const float* Dg, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s) {
   const int np = g.k1 - g.k0;
   dim3 grid = wl_plane_grid(g, wl_red_slots(g, np));
   DSEL(g.D, k_residual, grid, dim3(WL_BLOCK), 0, s, g, r, x, z, L, Dg, iD, ws.pa);
-  WL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
-  hipLaunchKernelGGL(k_mean_shift, wl_plane_grid(g, np), dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}));
   WL_LAUNCH_CHECK(); return 0;
+}
+int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s) {
+  hipLaunchKernelGGL(k_mean_shift, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}));
+  WL_LAUNCH_CHECK(); return 0;
+}
+int residual(float* r, const float* x, const float* z, const float* L, const float* Dg, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s) {
+  WL_TRY(residual_part(r, x, z, L, Dg, iD, g, ws, s));
+  return mean_shift(r, g, ws, s);
 }
 int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
   dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.k1 - g.k0));

@@ -184,21 +184,32 @@ struct wl_sim {
   float *u = nullptr, *u0 = nullptr, *f = nullptr, *p = nullptr, *sigma = nullptr, *V = nullptr, *mu0 = nullptr, *mu1 = nullptr;
   float* own = nullptr;
   wl_mg* mg = nullptr;
+  wl_comm* comm = nullptr;   // not owned; NULL for a single domain
   std::vector<float> dt;
   ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
 
-  int bc_u(hipStream_t s) { return wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s); }
+  // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
+  int bc_u(hipStream_t s) { WL_TRY(wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s)); return wl::halo(comm, u, G, d.D, 2, s); }
+  int bdim_step(float pre, float post, hipStream_t s) {
+    ProfScope pb(WL_PROF_BDIM, s);
+    if (d.has_body && comm) {   // μddn reads f[I±δz] across the slab face: exchange f between the two passes
+      WL_TRY(wl::bdim_f(f, u0, V, G, dt.back(), s));
+      WL_TRY(wl::halo(comm, f, G, d.D, 1, s));
+      return wl::bdim_u(u, f, V, mu0, mu1, G, pre, post, s);
+    }
+    return wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), pre, post, s);
+  }
   int exit_bc(hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
     { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
-    { ProfScope pb(WL_PROF_BDIM, s); WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 0.f, 1.f, s)); }   // scale_u!(a,0) folded (pre=0)
+    WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
     WL_TRY(bc_u(s));
     if (d.exitBC) WL_TRY(exit_bc(s));
     return 0;
   }
   int correct(hipStream_t s) {                                                           // mom_correct! :205-210
     { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
-    { ProfScope pb(WL_PROF_BDIM, s); WL_TRY(wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), 1.f, 0.5f, s)); }  // scale_u!(a,0.5) folded (post)
+    WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
   int project(float w, hipStream_t s) {                                                  // mom_project! :223-232
@@ -211,6 +222,7 @@ struct wl_sim {
   }
   int cfl(hipStream_t s) {                                                               // CFL :234-237
     WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s));
+    WL_TRY(wl::combine_results(comm, mg->ws, s));                                        // max over ranks
     float mx; WL_TRY(wl::read_results(mg->ws, nullptr, 0, &mx, 1, s));
     dt.push_back(std::fmin(10.f, 1.0f / (mx + 5 * d.nu)));
     return 0;
@@ -262,12 +274,19 @@ int wl_L2_inside(const float* a, const wl_grid* g, double* out, void* st) {
   return wl::read_results(ws, out, 1, nullptr, 0, s);
 }
 
-int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) {
+static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm) {
   WL_CHECK(out && desc, "null pointer"); WL_CHECK(desc->D == 2 || desc->D == 3, "D must be 2 or 3");
   WL_TRY(wl_ctx_ensure());
-  wl_sim* s = new wl_sim(); s->d = *desc;
+  const bool slab = comm && comm->size > 1;
+  wl_sim* s = new wl_sim(); s->d = *desc; s->comm = slab ? comm : nullptr;
   int32_t ng[3] = {desc->dims[0] + 2, desc->dims[1] + 2, desc->D == 3 ? desc->dims[2] + 2 : 1};
-  s->g = wl_grid_single(desc->D, ng); s->G = gx(s->g);
+  if (slab) {
+    if (desc->exitBC) { delete s; wl_set_error("exitBC on z-slabs is not supported this round"); return WL_EINVAL; }
+    if (desc->u || desc->u0 || desc->f || desc->p || desc->sigma || desc->V || desc->mu0 || desc->mu1) { delete s; wl_set_error("slab simulations own their arrays"); return WL_EINVAL; }
+    const int rc = wl_grid_slab(&s->g, desc->D, ng, comm->rank, comm->size, 2);
+    if (rc != 0) { delete s; return rc; }
+  } else s->g = wl_grid_single(desc->D, ng);
+  s->G = gx(s->g);
   const size_t nc = (size_t)s->G.cs; const int D = desc->D;
   float** ptrs[8] = {&s->u, &s->u0, &s->f, &s->p, &s->sigma, &s->V, &s->mu0, &s->mu1};
   float* given[8] = {desc->u, desc->u0, desc->f, desc->p, desc->sigma, desc->V, desc->mu0, desc->mu1};
@@ -286,12 +305,16 @@ int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) {
   if (!desc->mu0) {
     int rc = wl::fill(s->mu0, 1.f, nc * D, 0); const float zero[3] = {0, 0, 0};
     if (rc == 0) rc = wl::bc_vec(s->mu0, s->G, zero, 0, desc->perdir_mask, 0);
+    if (rc == 0) rc = wl::halo(s->comm, s->mu0, s->G, D, 2, 0);
     if (rc != 0) { delete s; return rc; }
   }
-  int rc = wl_mg_create(&s->mg, s->p, s->mu0, s->sigma, &s->g, desc->perdir_mask, 10);   // pois_ctor default  src/WaterLily.jl:97
+  s->mg = new wl_mg();
+  int rc = s->mg->build(s->p, s->mu0, s->sigma, s->g, desc->perdir_mask, 10, s->comm);   // pois_ctor default  src/WaterLily.jl:97
   if (rc != 0) { delete s; *out = nullptr; return rc; }
   *out = s; return 0;
 }
+int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) { return sim_create_common(out, desc, nullptr); }
+int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm) { return sim_create_common(out, desc, comm); }
 int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
 float* wl_sim_field(wl_sim* s, const char* name) {
   const std::string n(name);
@@ -350,6 +373,7 @@ int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* s
   const float zero[3] = {0, 0, 0};
   WL_TRY(wl::bc_vec(s->mu0, G, zero, 0, s->d.perdir_mask, q));                                                                     // Body.jl:49
   WL_TRY(wl::bc_vec(s->V, G, zero, s->d.exitBC, s->d.perdir_mask, q));                                                              // Body.jl:50
+  WL_TRY(wl::halo(s->comm, s->mu0, G, D, 2, q)); WL_TRY(wl::halo(s->comm, s->V, G, D, 2, q));
   return s->mg->update(q);                                                                                                          // WaterLily.jl:148
 }
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {

@@ -1,0 +1,249 @@
+"""z-slab multi-GPU path (one process per GPU): communicator construction and the slab Simulation.
+
+The reference has no multi-device path (README.md:153-155) — this is new design: every rank owns Nz/P interior
+x-y planes (+2 ghost planes per side), stencil kernels index cells globally (colour parity, wall faces), halos
+are single contiguous planes, coarse multigrid levels are replicated on every rank below 32 planes, and the
+scalars that steer the solver are combined on device from an all-gather so all ranks branch identically.
+Transport: RCCL (ncclSend/ncclRecv/ncclAllGather on the compute stream, over xGMI) in production; for tests a
+callback communicator moves the same buffers through torch.distributed (gloo) and host memory.
+"""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+from ._lib import ALLGATHER_FN, SENDRECV_FN, check, lib, wl_grid, wl_sim_desc
+from .core import perdir_mask
+
+
+def slab_grid(global_dims_with_ghosts, rank, size, halo=2):
+    """wl_grid of `rank` (host helper of the library — no GPU needed)."""
+    g = wl_grid()
+    arr = (C.c_int32 * 3)(*global_dims_with_ghosts)
+    check(lib().wl_grid_slab(C.byref(g), 3, arr, rank, size, halo))
+    return g
+
+
+class CallbackComm:
+    """wl_comm whose transport is torch.distributed point-to-point / all_gather on HOST tensors (gloo).
+
+    stage_out(dst_numpy_uint8, src_ptr, nbytes) / stage_in(dst_ptr, src_numpy_uint8, nbytes) move bytes between the
+    library's buffers and host memory: wl_d2h / wl_h2d on a GPU, plain memmove when the 'device' buffers are host
+    arrays (CPU tests of the halo plumbing)."""
+
+    def __init__(self, dist, rank=None, size=None, host_buffers=False):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.rank = dist.get_rank() if rank is None else rank
+        self.size = dist.get_world_size() if size is None else size
+        L = lib()
+        if host_buffers:
+            self._out = lambda dst, src, n: C.memmove(dst.ctypes.data, src, n)
+            self._in = lambda dst, src, n: C.memmove(dst, src.ctypes.data, n)
+            self._sync = lambda st: None
+        else:
+            self._out = lambda dst, src, n: check(L.wl_d2h(dst.ctypes.data_as(C.c_void_p), src, n, None))
+            self._in = lambda dst, src, n: (check(L.wl_h2d(dst, src.ctypes.data_as(C.c_void_p), n, None)), check(L.wl_stream_sync(None)))
+            self._sync = lambda st: check(L.wl_stream_sync(st))
+        self._sr = SENDRECV_FN(self._sendrecv)
+        self._ag = ALLGATHER_FN(self._allgather)
+        h = C.c_void_p()
+        check(L.wl_comm_callbacks_create(C.byref(h), self.rank, self.size, None, C.cast(self._sr, C.c_void_p), C.cast(self._ag, C.c_void_p)))
+        self.handle = h
+
+    def _sendrecv(self, ctx, slo, rlo, shi, rhi, nbytes, stream):
+        try:
+            torch, dist = self.torch, self.dist
+            self._sync(stream)
+            reqs, keep = [], []
+            if slo:
+                b = np.empty(nbytes, dtype=np.uint8); self._out(b, slo, nbytes); t = torch.from_numpy(b); keep.append(t)
+                reqs.append(dist.isend(t, self.rank - 1))
+            if shi:
+                b = np.empty(nbytes, dtype=np.uint8); self._out(b, shi, nbytes); t = torch.from_numpy(b); keep.append(t)
+                reqs.append(dist.isend(t, self.rank + 1))
+            rl = rh = None
+            if rlo:
+                rl = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rl, self.rank - 1))
+            if rhi:
+                rh = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rh, self.rank + 1))
+            for r in reqs:
+                r.wait()
+            if rl is not None:
+                self._in(rlo, rl.numpy(), nbytes)
+            if rh is not None:
+                self._in(rhi, rh.numpy(), nbytes)
+            return 0
+        except Exception as e:  # never let an exception cross the C boundary
+            print("halo callback error:", repr(e), flush=True)
+            return 1
+
+    def _allgather(self, ctx, send, recv, nbytes, stream):
+        try:
+            torch, dist = self.torch, self.dist
+            self._sync(stream)
+            b = np.empty(nbytes, dtype=np.uint8); self._out(b, send, nbytes)
+            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.size)]
+            dist.all_gather(outs, torch.from_numpy(b))
+            for r, t in enumerate(outs):
+                self._in(recv + r * nbytes, t.numpy(), nbytes)
+            return 0
+        except Exception as e:
+            print("allgather callback error:", repr(e), flush=True)
+            return 1
+
+    def destroy(self):
+        if self.handle:
+            lib().wl_comm_destroy(self.handle)
+            self.handle = None
+
+
+class RcclComm:
+    """wl_comm over RCCL: the unique id is created on rank 0 and broadcast through torch.distributed."""
+
+    def __init__(self, dist, device):
+        import torch
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+        uid = C.create_string_buffer(128)
+        if self.rank == 0:
+            check(lib().wl_comm_rccl_unique_id(uid))
+        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
+        if dist.get_backend() == "nccl":
+            t = t.to(device)
+        dist.broadcast(t, 0)
+        raw = bytes(t.cpu().numpy().tobytes())
+        h = C.c_void_p()
+        check(lib().wl_comm_rccl_create(C.byref(h), self.rank, self.size, raw))
+        self.handle = h
+
+    def destroy(self):
+        if self.handle:
+            lib().wl_comm_destroy(self.handle)
+            self.handle = None
+
+
+class SlabSimulation:
+    """Simulation on a z-slab (wl_sim_create_slab): same step as FusedSimulation, fields distributed along z."""
+
+    def __init__(self, comm, dims, uBC, L, U=None, dt=0.25, nu=0.0, perdir=(), lam=0, has_body=False, ic="uBC"):
+        D = 3
+        assert len(dims) == 3
+        if U is None:
+            U = float(np.sqrt(sum(float(v) ** 2 for v in uBC)))
+        self.comm, self.U, self.L, self.D = comm, float(U), float(L), D
+        self.dims = tuple(int(n) for n in dims)
+        d = wl_sim_desc()
+        d.D = D
+        for k in range(3):
+            d.dims[k] = self.dims[k]
+            d.uBC[k] = float(uBC[k])
+        d.nu, d.dt0 = float(nu), float(dt)
+        d.perdir_mask, d.exitBC, d.scheme, d.has_body = perdir_mask(perdir), 0, int(lam), int(bool(has_body))
+        h = C.c_void_p()
+        check(lib().wl_sim_create_slab(C.byref(h), C.byref(d), comm.handle))
+        self._h = h
+        g = wl_grid()
+        check(lib().wl_sim_grid(h, C.byref(g)))
+        self.grid = g
+        check(lib().wl_sim_apply_ic(h, {"uBC": 0, "tgv": 1}[ic], None))
+        check(lib().wl_sim_init_flow(h, None))
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().wl_sim_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def mom_step_(self):
+        check(lib().wl_sim_mom_step(self._h, None))
+
+    def sync(self):
+        check(lib().wl_stream_sync(None))
+
+    @property
+    def dt(self):
+        out = (C.c_float * 100000)()
+        k = lib().wl_sim_dt(self._h, out, 100000)
+        return [np.float32(v) for v in out[:k]]
+
+    @property
+    def pois_n(self):
+        out = (C.c_int16 * 65536)()
+        k = lib().wl_mg_history(lib().wl_sim_pois(self._h), out, 65536)
+        return [int(v) for v in out[:k]]
+
+    def local_field(self, name):
+        """this rank's slab (all local planes incl. ghosts), Fortran order"""
+        g = self.grid
+        nc = {"p": (), "sigma": ()}.get(name, (3,))
+        out = np.empty((g.nx, g.ny, g.nz) + nc, dtype=np.float32, order="F")
+        check(lib().wl_d2h(out.ctypes.data_as(C.c_void_p), lib().wl_sim_field(self._h, name.encode()), out.nbytes, None))
+        return out
+
+    def gather_field(self, name, dist):
+        """assemble the global ghosted array on every rank from the owned planes (+ the physical z-ghost planes)"""
+        import torch
+        g = self.grid
+        loc = self.local_field(name)
+        lo = g.k0 - (1 if g.gk + g.k0 == 1 else 0)
+        hi = g.k1 + (1 if g.gk + g.k1 == g.gnz - 1 else 0)
+        mine = np.ascontiguousarray(loc[:, :, lo:hi])
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, (g.gk + lo, mine))
+        nc = mine.shape[3:]
+        full = np.zeros((g.nx, g.ny, g.gnz) + nc, dtype=np.float32, order="F")
+        for z0, a in parts:
+            full[:, :, z0:z0 + a.shape[2]] = a
+        return full
+
+
+def make_comm(dist, device, prefer="rccl"):
+    if prefer == "rccl" and dist.get_backend() == "nccl":
+        return RcclComm(dist, device)
+    return CallbackComm(dist)
+
+
+def bench_main(args, world, rank, local_rank):
+    """bench.py --gpus N (N>1): the same 512³ TGV cut into N z-slabs (strong scaling), one process per GPU."""
+    import torch
+    import torch.distributed as dist
+    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("WL_DIST_BACKEND", "nccl")
+    dist.init_process_group(backend=backend, device_id=dev if backend == "nccl" else None)
+    comm = make_comm(dist, dev)
+    N = args.size
+    sim = SlabSimulation(comm, (N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+    for _ in range(args.warmup):
+        sim.mom_step_()
+    sim.sync()
+    n_warm = len(sim.pois_n)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.mom_step_()
+    torch.cuda.synchronize()
+    dist.barrier()
+    el = time.perf_counter() - t0
+    t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+    if rank == 0:
+        pn = sim.pois_n[n_warm:]
+        out = {"metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": float(N) ** 3 * args.steps / el, "unit": "cells*steps/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false, {world} z-slabs",
+                          "size": N, "parallelism": f"zslab{world}", "transport": type(comm).__name__, "mean_pois_n": float(sum(pn)) / max(1, len(pn)),
+                          "dt_last": float(sim.dt[-1])},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    del sim
+    comm.destroy()
+    dist.destroy_process_group()
