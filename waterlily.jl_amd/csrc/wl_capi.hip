@@ -1,6 +1,7 @@
 // C ABI of libwlhip.so (see include/wlhip.h): context, leaf wrappers and the MultiLevelPoisson handle.
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "wl_common.hpp"
@@ -123,10 +124,14 @@ int wl_mg::update(hipStream_t s) {                                              
 int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
   Level& p = lv[(size_t)l];
   ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
-  WL_TRY(wl::gs_init(p.eps, p.r, p.iD, p.x_, s));
-  WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));
-  WL_TRY(halo(p, p.eps, 1, s));
-  for (int k0 = 1; k0 <= it; k0++) {
+  const bool fuse = !perdir && !p.dist && it >= 1;   // ghost ϵ are plain memory reads only on these levels
+  if (fuse) WL_TRY(wl::gs_init_sweep1(p.eps, p.r, p.L, p.iD, p.x_, s));
+  else {
+    WL_TRY(wl::gs_init(p.eps, p.r, p.iD, p.x_, s));
+    WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));
+    WL_TRY(halo(p, p.eps, 1, s));
+  }
+  for (int k0 = fuse ? 2 : 1; k0 <= it; k0++) {
     ProfScope pk(l == 0 ? WL_PROF_GS_SWEEP : -1, s);
     WL_TRY(wl::gs_sweep(p.eps, p.r, p.L, p.iD, p.x_, k0, s));
     WL_TRY(halo(p, p.eps, 1, s));                                                          // neighbour slabs need this colour before the next sweep
@@ -139,10 +144,15 @@ int wl_mg::vcycle(int l, float w, hipStream_t s) {                              
   // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
   {
     ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
-    WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
-    WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
-    WL_TRY(halo(fine, fine.eps, 1, s));
-    WL_TRY(wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, 1.f, s));
+    if (!perdir && !fine.dist) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
+      WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, s));
+      std::swap(fine.r, fine.eps);
+    } else {
+      WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
+      WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+      WL_TRY(halo(fine, fine.eps, 1, s));
+      WL_TRY(wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, 1.f, s));
+    }
   }
   {
     ProfScope pc(l == 0 ? WL_PROF_COARSE : -1, s);   // everything below the finest level
@@ -174,8 +184,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     WL_TRY(halo(p, p.x, 1, s));
     WL_TRY(wl::residual_part(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));               // r and the local Σr -> res_d[0]
     WL_TRY(wl::combine_results(comm, ws, s));
-    WL_TRY(wl::mean_shift(p.r, p.x_, ws, s));
-    WL_TRY(wl::norms_dev(p.r, p.x_, ws, 1, 0, s));                                        // r₁ -> res_d[1], r∞ -> res_f[0]
+    WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));                                  // mean shift + r₁ -> res_d[1], r∞ -> res_f[0]
   }
   double hd[3]; float hf[2];
   float w = 1.f;

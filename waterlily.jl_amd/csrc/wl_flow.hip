@@ -63,11 +63,9 @@ __global__ void k_fin_max(const float* __restrict__ pmax, int n, float* __restri
 }
 
 // ---- convective schemes   src/Flow.jl:4-6,27-36 --------------------------------------------------
-__device__ __forceinline__ float median3(float a, float b, float c) {
-  if (a > b) { if (b >= c) return b; if (a > c) return c; }
-  else       { if (b <= c) return b; if (a < c) return c; }
-  return a;
-}
+// median(a,b,c) src/Flow.jl:27-36 — one v_med3_f32; identical value to the reference's branchy form for non-NaN inputs
+// (the branchy form compiled to ~700 exec-mask instructions per cell in conv_diff!).
+__device__ __forceinline__ float median3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
 template <int SCH> __device__ __forceinline__ float lam(float u, float c, float d) {
   if (SCH == WL_QUICK) return median3((5 * c + 2 * d - u) / 6, c, median3(10 * c - 9 * u, c, d));
   if (SCH == WL_VANLEER) return (c <= fminf(u, d) || c >= fmaxf(u, d)) ? c : c + (d - c) * (c - u) / (d - u);
@@ -108,57 +106,104 @@ __device__ __forceinline__ float flux_upperR(const float* __restrict__ f, const 
 // One thread per cell of the WHOLE array (r .= 0 included).  For cell I (Julia indices) and component a:
 //   r[I,a] = Σ_b [ +Φ_ab(I) − Φ_ab(I+δ_b) ]  taken in the reference's (j inner) order, direction b
 //   contributing iff I_b ∈ 2..Ng_b−1 and every other I_c ∈ 2..Ng_c (upper ghost INCLUDED, as inside_u does).
-template <int D, int SCH>
-__global__ void k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float* __restrict__ Phi, float nu, unsigned per, int kfirst) {
+// Straight-line, fully unrolled and predicated: every load of the (a,b) pair is independent of the others (the
+// first version kept the a/b loops rolled — 32 VGPRs, one long chain of dependent loads, 6.4 ms at 512³).
+// One flux formula serves all face variants:
+//   Φ = U·X − ν(f[P]−f[P−δ]),  X = λ(upwind triple by sign of U), overridden by the plain average ϕ where the
+//   reference uses ϕuL (lower wall, U>0) / ϕuR (upper wall, U<0); periodic lower faces only change the address
+//   of the far-upwind point (ϕuP).  r[I−δ] += −ϕuR+ν∂ equals r[I−δ] −= (ϕuR−ν∂) bit for bit, so the upper wall
+//   needs no separate accumulation form.  Addresses that a masked lane would take out of range are clamped to
+//   its own cell (values unused).
+template <int SCH>
+__device__ __forceinline__ float face_flux(float U, float t0, float t1, float t2, float avg, bool use_avg, float fc, float fm, float nu) {
+  float X = lam<SCH>(t0, t1, t2);
+  X = use_avg ? avg : X;
+  return U * X - nu * (fc - fm);
+}
+// PER = 0: no periodic direction (no wrapped addresses, no branches at all); IDX = int when every component offset fits 31 bits
+template <int D, int SCH, int PER, typename IDX>
+__global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const int k = (D == 3) ? kfirst + (int)pz : 0;
-  const long o = m + (long)k * g.sz;
+  const int k = (D == 3) ? kfirst + pz : 0;
+  const IDX o = (IDX)(m + (long)k * g.sz);
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2};    // Julia (global) indices
   const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
-  const long st[3] = {1, g.sy, g.sz};
-  bool all_ge2 = true;
-  for (int c = 0; c < D; c++) all_ge2 = all_ge2 && (I[c] >= 2);
+  const IDX st[3] = {1, (IDX)g.sy, (IDX)g.sz};
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < D; c++) ok = ok && (I[c] >= 2);
+  float out[3];
+#pragma unroll
   for (int a = 0; a < D; a++) {
     const float* __restrict__ f = u + (long)a * g.cs;
+    const IDX sa = ok ? st[a] : 0;
     float acc = 0.f;
-    if (all_ge2) {
-      for (int b = 0; b < D; b++) {
-        if (I[b] > N[b] - 1) continue;
-        const float* __restrict__ ub = u + (long)b * g.cs;
-        const long sb = st[b], sa = st[a];
-        const bool pb = (per >> b) & 1u;
-        // + flux at my own lower face
-        if (I[b] == 2) acc += pb ? flux_lowerP<SCH>(f, ub, o, sb, sa, nu, o + (long)(N[b] - 2 - I[b]) * sb) : flux_lowerL<SCH>(f, ub, o, sb, sa, nu);
-        else acc += flux_inner<SCH>(f, ub, o, sb, sa, nu);
-        // − flux at my upper face (= lower face of I+δ_b)
-        const long on = o + sb;
-        if (I[b] + 1 == N[b]) {
-          if (pb) { const long o2 = o + (long)(2 - I[b]) * sb; acc -= flux_lowerP<SCH>(f, ub, o2, sb, sa, nu, o2 + (long)(N[b] - 4) * sb); }   // Φ[CIj(j,I,2)] :62
-          else acc += flux_upperR<SCH>(f, ub, on, sb, sa, nu);
-        } else acc -= flux_inner<SCH>(f, ub, on, sb, sa, nu);
+    const float f0 = f[o];
+#pragma unroll
+    for (int b = 0; b < D; b++) {
+      const float* __restrict__ ub = u + (long)b * g.cs;
+      const bool pb = PER && ((per >> b) & 1u);
+      const bool con = ok && (I[b] <= N[b] - 1);
+      const bool lowb = (I[b] == 2), upb = (I[b] + 1 == N[b]);
+      const IDX sb = con ? st[b] : 0;
+      // star of f along b, clamped where the variant never reads it
+      const IDX om2 = lowb ? (pb ? (IDX)(N[b] - 4) * sb : -sb) : -2 * sb;       // far upwind of my lower face (ϕuP wraps)
+      const IDX op2 = (I[b] + 2 <= N[b]) ? 2 * sb : sb;                          // far downwind of my upper face
+      const float fm2 = f[o + om2], fm1 = f[o - sb], fp1 = f[o + sb], fp2 = f[o + op2];
+      // lower face of I: U = ϕ(a, CI(I,b), u) = (u_b[I] + u_b[I−δ_a])/2        src/Flow.jl:3,47
+      const float Ul = (ub[o] + ub[o - sa]) / 2;
+      const bool posl = Ul > 0;
+      const float Pl = face_flux<SCH>(Ul, posl ? fm2 : fp1, posl ? fm1 : f0, posl ? f0 : fm1, (f0 + fm1) / 2, lowb && !pb && posl, f0, fm1, nu);
+      // upper face of I = lower face of I+δ_b
+      float Pu;
+      if (PER && upb && pb) {   // periodic: Φ[CIj(j,I,2)] — the wrapped lower-face flux at index 2   src/Flow.jl:62 (rare plane)
+        const long o2 = (long)o + (long)(2 - I[b]) * sb;
+        Pu = flux_lowerP<SCH>(f, ub, o2, sb, sa, nu, o2 + (long)(N[b] - 4) * sb);
+      } else {
+        const float Uu = (ub[o + sb] + ub[o + sb - sa]) / 2;
+        const bool posu = Uu > 0;
+        Pu = face_flux<SCH>(Uu, posu ? fm1 : fp2, posu ? f0 : fp1, posu ? fp1 : f0, (fp1 + f0) / 2, upb && !pb && (Uu < 0), fp1, f0, nu);
       }
+      acc = con ? acc + Pl : acc;
+      acc = con ? acc - Pu : acc;
     }
-    r[(long)a * g.cs + o] = acc;
+    out[a] = acc;
   }
-  // Quirk Q1: Φ≡σ keeps the fluxes of the LAST pass that covered a cell; interior values are
-  // overwritten by div/flux_out later, so only upper-ghost cells matter for CFL's maximum(σ).  Reproduce them.
-  if (Phi != nullptr && all_ge2) {
-    bool ghost = false;
-    for (int c = 0; c < D; c++) ghost = ghost || (I[c] == N[c]);
-    if (ghost) {
-      const int a = D - 1;
-      const float* __restrict__ f = u + (long)a * g.cs;
-      for (int b = D - 1; b >= 0; b--) {
-        const bool pb = (per >> b) & 1u;
-        const bool covered = (I[b] >= 3 && I[b] <= N[b] - 1) || (pb && I[b] == 2);
-        if (!covered) continue;
-        const float* __restrict__ ub = u + (long)b * g.cs;
-        Phi[o] = (I[b] == 2) ? flux_lowerP<SCH>(f, ub, o, st[b], st[a], nu, o + (long)(N[b] - 4) * st[b]) : flux_inner<SCH>(f, ub, o, st[b], st[a], nu);
-        break;
-      }
-    }
+#pragma unroll
+  for (int a = 0; a < D; a++) r[(long)a * g.cs + o] = out[a];
+}
+// Quirk Q1: Φ≡σ keeps the fluxes of the LAST pass that covered a cell; interior values are
+// overwritten by div/flux_out later, so only upper-ghost cells matter for CFL's maximum(σ).  Reproduced by this
+// small kernel over the three upper ghost planes (blockIdx.y = direction whose index is Ng).
+template <int D, int SCH>
+__global__ void k_conv_q1(GridX g, float* __restrict__ Phi, const float* __restrict__ u, float nu, unsigned per) {
+  const int d = blockIdx.y;
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
+  const long st[3] = {1, g.sy, g.sz};
+  const int d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+  const int n1 = (d1 == 0) ? g.nx : g.ny;
+  const long cnt = (long)n1 * ((D == 3) ? ((d2 == 1) ? g.ny : g.nz) : 1);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  int loc[3] = {0, 0, 0};
+  loc[d1] = (int)(q % n1);
+  if (D == 3) loc[d2] = (int)(q / n1);
+  if (d == 2) { const int kl = N[2] - 1 - g.gk; if (kl < 0 || kl >= g.nz) return; loc[2] = kl; } else loc[d] = N[d] - 1;
+  const int I[3] = {loc[0] + 1, loc[1] + 1, (D == 3) ? g.gk + loc[2] + 1 : 2};
+  if (D == 3 && d != 2) { const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || I[2] == N[2]; if (!owned) return; }
+  for (int c = 0; c < D; c++) if (I[c] < 2) return;
+  const long o = (long)loc[0] + (long)loc[1] * g.sy + (long)loc[2] * g.sz;
+  const int a = D - 1;
+  const float* __restrict__ f = u + (long)a * g.cs;
+  for (int b = D - 1; b >= 0; b--) {
+    const bool pb = (per >> b) & 1u;
+    const bool covered = (I[b] >= 3 && I[b] <= N[b] - 1) || (pb && I[b] == 2);
+    if (!covered) continue;
+    const float* __restrict__ ub = u + (long)b * g.cs;
+    Phi[o] = (I[b] == 2) ? flux_lowerP<SCH>(f, ub, o, st[b], st[a], nu, o + (long)(N[b] - 4) * st[b]) : flux_inner<SCH>(f, ub, o, st[b], st[a], nu);
+    break;
   }
 }
 
@@ -438,19 +483,36 @@ int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s) {
   WL_LAUNCH_CHECK(); return 0;
 }
 
-template <int D>
-static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
+template <int D, int SCH>
+static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s) {
   // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
-  dim3 grid = wl_plane_grid(g, klast - kfirst);
-  switch (scheme) {
-    case WL_QUICK: hipLaunchKernelGGL((k_conv_diff<D, WL_QUICK>), grid, dim3(WL_BLOCK), 0, s, g, r, u, Phi, nu, per, kfirst); break;
-    case WL_VANLEER: hipLaunchKernelGGL((k_conv_diff<D, WL_VANLEER>), grid, dim3(WL_BLOCK), 0, s, g, r, u, Phi, nu, per, kfirst); break;
-    case WL_CDS: hipLaunchKernelGGL((k_conv_diff<D, WL_CDS>), grid, dim3(WL_BLOCK), 0, s, g, r, u, Phi, nu, per, kfirst); break;
-    default: wl_set_error("unknown scheme"); return WL_EINVAL;
+  const dim3 grid = wl_plane_grid(g, klast - kfirst);
+  const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
+  if (per) {
+    if (small) hipLaunchKernelGGL((k_conv_diff<D, SCH, 1, int>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
+    else hipLaunchKernelGGL((k_conv_diff<D, SCH, 1, long>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
+  } else {
+    if (small) hipLaunchKernelGGL((k_conv_diff<D, SCH, 0, int>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
+    else hipLaunchKernelGGL((k_conv_diff<D, SCH, 0, long>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
+  }
+  if (Phi) {
+    long cmax = (long)g.ny * (D == 3 ? g.nz : 1);
+    cmax = cmax > (long)g.nx * (D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (D == 3 ? g.nz : 1);
+    cmax = cmax > g.sz ? cmax : g.sz;
+    hipLaunchKernelGGL((k_conv_q1<D, SCH>), dim3((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)D, 1), dim3(WL_BLOCK), 0, s, g, Phi, u, nu, per);
   }
   WL_LAUNCH_CHECK(); return 0;
+}
+template <int D>
+static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
+  switch (scheme) {
+    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s);
+    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s);
+    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s);
+  }
+  wl_set_error("unknown scheme"); return WL_EINVAL;
 }
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
   return g.D == 3 ? conv_diff_launch<3>(r, u, Phi, g, nu, per, scheme, s) : conv_diff_launch<2>(r, u, Phi, g, nu, per, scheme, s);

@@ -160,6 +160,77 @@ __global__ void k_gs_sweep(GridX g, float* __restrict__ eps, const float* __rest
   eps[o] = s * iD[o];
 }
 
+// ---- fused variants used by the V-cycle on non-periodic, non-distributed levels -------------------------------
+// ϵ at a neighbour before any sweep: r·iD for an interior cell (bit-identical to what gs_init stores), the stored
+// ghost value otherwise (ghosts of ϵ are never written by the smoother).
+template <int D>
+__device__ __forceinline__ bool is_inside(const GridX& g, int i, int j, int k) {
+  bool in = i >= 1 && i <= g.nx - 2 && j >= 1 && j <= g.ny - 2;
+  if (D == 3) in = in && k >= g.k0 && k < g.k1;
+  return in;
+}
+// GaussSeidelRB!: `ϵ = r·iD` and the first colour sweep in ONE pass (24 instead of 12+28 B/cell)   src/Poisson.jl:142-145
+template <int D>
+__global__ void k_gs_init_sweep1(GridX g, float* __restrict__ eps, const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ iD) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const int k = g.k0 + pz;
+  const int K = (D == 3) ? g.gk + k : 0;
+  const long o = m + (long)k * g.sz;
+  const float e0 = r[o] * iD[o];
+  bool upd = ((i + j + K + D + 1) & 1) != 0;                                    // colour of sweep k₀=1
+  if (D == 3) upd = upd && !(K + 1 > 2 * (g.gnz / 2) - 1); else upd = upd && !(j + 1 > 2 * (g.ny / 2) - 1);   // quirk Q4
+  if (!upd) { eps[o] = e0; return; }
+  auto E = [&](long oo, bool in) -> float { return in ? r[oo] * iD[oo] : eps[oo]; };
+  float s = r[o];
+  s -= (E(o - 1, i > 1) * L[o] + E(o + 1, i < g.nx - 2) * L[o + 1]);
+  s -= (E(o - g.sy, j > 1) * L[g.cs + o] + E(o + g.sy, j < g.ny - 2) * L[g.cs + o + g.sy]);
+  if (D == 3) s -= (E(o - g.sz, k > g.k0) * L[2 * g.cs + o] + E(o + g.sz, k < g.k1 - 1) * L[2 * g.cs + o + g.sz]);
+  eps[o] = s * iD[o];
+}
+// Jacobi!(it=1,ω): ϵ=r·iD ; r -= ωAϵ ; x += ωϵ in ONE pass.  The new residual goes to `rout` (≠ r: neighbours still read
+// the old r); the caller then swaps its r/ϵ buffers.  36 instead of 12+36 B/cell.                 src/Poisson.jl:111-114
+template <int D>
+__global__ void k_jacobi_pp(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, const float* __restrict__ L,
+                            const float* __restrict__ Dg, const float* __restrict__ iD, float w) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const int k = g.k0 + pz;
+  const long o = m + (long)k * g.sz;
+  // rout's ghost cells hold the (zero) ghosts of the buffer that used to be ϵ: both are zero on these levels
+  auto E = [&](long oo, bool in) -> float { return in ? r[oo] * iD[oo] : rout[oo]; };
+  const float e0 = r[o] * iD[o];
+  float s = e0 * Dg[o];
+  s += (E(o - 1, i > 1) * L[o] + E(o + 1, i < g.nx - 2) * L[o + 1]);
+  s += (E(o - g.sy, j > 1) * L[g.cs + o] + E(o + g.sy, j < g.ny - 2) * L[g.cs + o + g.sy]);
+  if (D == 3) s += (E(o - g.sz, k > g.k0) * L[2 * g.cs + o] + E(o + g.sz, k < g.k1 - 1) * L[2 * g.cs + o + g.sz]);
+  rout[o] = r[o] - w * s;
+  x[o] = x[o] + w * e0;
+}
+// residual!'s mean shift and L₁/L∞ of the shifted residual in ONE pass   src/Poisson.jl:95-97,190-191
+__global__ void k_shift_norms(GridX g, float* __restrict__ r, const double* __restrict__ sum, double n_inside, double* __restrict__ part, float* __restrict__ pmax) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  const float s = (float)(*sum) / (float)n_inside;
+  const bool shift = !(fabsf(s) <= 2.f * 1.1920929e-7f);
+  double acc = 0.0; float mx = 0.f;
+  const int nsl = wl_nslots(g);
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) {
+      const long o = m + (long)k * g.sz;
+      float v = r[o];
+      if (shift) { v = v - s; r[o] = v; }
+      const float av = fabsf(v);
+      acc += (double)av; mx = fmaxf(mx, av);
+    }
+  }
+  acc = block_sum(acc);
+  mx = block_max(mx);
+  if (threadIdx.x == 0) { part[blockIdx.x] = acc; pmax[blockIdx.x] = mx; }
+}
+
 // restrict!  a[I] = Σ_{J∈up(I,c)} b[J]   src/MultiLevelPoisson.jl:6,13-19,49  (children summed x fastest, like CartesianIndices)
 template <int D>
 __global__ void k_restrict(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
@@ -293,6 +364,20 @@ int jacobi(float* eps, float* r, float* x, const float* L, const float* Dg, cons
 }
 int gs_init(float* eps, const float* r, const float* iD, const GridX& g, hipStream_t s) {
   hipLaunchKernelGGL(k_gs_init, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, iD);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s) {
+  DSEL(g.D, k_gs_init_sweep1, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, L, iD);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, hipStream_t s) {
+  DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
+  dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.k1 - g.k0));
+  hipLaunchKernelGGL(k_shift_norms, grid, dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}), ws.pa, ws.pm);
+  hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)grid.x, ws.res_d + slot_d, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const GridX& g, int k0, hipStream_t s) {

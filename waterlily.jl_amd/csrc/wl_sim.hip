@@ -3,6 +3,7 @@
 // closed-form sphere measure!, pressure_force) and exitBC!, L₂.
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "wl_common.hpp"
@@ -185,6 +186,7 @@ struct wl_sim {
   float* own = nullptr;
   wl_mg* mg = nullptr;
   wl_comm* comm = nullptr;   // not owned; NULL for a single domain
+  bool swap_ok = false;      // u and u⁰ are handle-owned and every ghost of u is rewritten by BC! (no exitBC)
   std::vector<float> dt;
   ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
 
@@ -229,7 +231,10 @@ struct wl_sim {
   }
   int mom_step(hipStream_t s) {                                                          // mom_step! :156-167
     ProfScope pstep(WL_PROF_STEP, s);
-    WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s));   // u⁰ .= u
+    // u⁰ .= u ; scale_u!(a,0): when the handle owns both arrays the copy is a pointer swap — the predictor overwrites
+    // every interior cell of u (BDIM! with pre=0) and BC! every ghost cell, so nothing of the old u survives anyway.
+    if (swap_ok) std::swap(u, u0);
+    else WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s));   // u⁰ .= u
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s));
     WL_TRY(correct(s));
@@ -301,6 +306,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     else { *ptrs[q] = pcur; pcur += sz[q]; }
   }
   s->dt.assign(1, desc->dt0);
+  s->swap_ok = !desc->u && !desc->u0 && !desc->exitBC;
   // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
   if (!desc->mu0) {
     int rc = wl::fill(s->mu0, 1.f, nc * D, 0); const float zero[3] = {0, 0, 0};
