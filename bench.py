@@ -22,8 +22,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ≈6.3 achievable)
 # algorithmic bytes per interior cell (SURVEY §8d / BASELINE.md §4), f32, 3-D
-BYTES_GS_SWEEP = 20.0     # one colour sweep as its own pass: R ½r,½iD,L₁₋₃,½ϵ  W ½ϵ
 BYTES_SMOOTH_OP = 40.0    # GaussSeidelRB!(it=4) as ONE operation: R r,iD,L₁₋₃,D,x  W ϵ,r,x
+BYTES_GS_A = 24.0         # kernel A of the temporally blocked smoother: R r,iD,L₁₋₃  W ϵ_mid
+BYTES_GS_B = 44.0         # kernel B: R ϵ_mid,r,iD,L₁₋₃,D,x  W ϵ,r',x
 
 
 def cpu_baseline(n=128, warm=2, steps=None, budget_s=12.0):
@@ -112,7 +113,8 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     prof = {}
-    names = {0: "gs_sweep", 1: "smooth", 2: "jacobi", 3: "conv_diff", 4: "residual", 5: "bdim", 6: "prolong_increment", 7: "coarse_levels", 8: "mom_step"}
+    names = {0: "gs_sweep", 1: "smooth", 2: "jacobi", 3: "conv_diff", 4: "residual", 5: "bdim", 6: "prolong_increment", 7: "coarse_levels", 8: "mom_step",
+             9: "gsrb_A", 10: "gsrb_B"}
     for slot, nm in names.items():
         cnt, tot = C.c_int(), C.c_double()
         check(lib.wl_prof_read(slot, C.byref(cnt), C.byref(tot)))
@@ -120,9 +122,9 @@ def main():
     check(lib.wl_prof_enable(0))
     ncell = float(N) ** 3
     pn = sim.pois_n[n_warm:]
-    # dominant kernel: the finest-level red–black colour sweep (4 launches per smooth!)
-    sweep_ms = prof["gs_sweep"]["avg_ms"]
-    ach = BYTES_GS_SWEEP * ncell / (sweep_ms * 1e-3) / 1e9
+    # dominant kernel: kernel B of the temporally blocked smoother (sweeps 3,4 + increment!) on the finest level
+    kb_ms, ka_ms = prof["gsrb_B"]["avg_ms"], prof["gsrb_A"]["avg_ms"]
+    ach = BYTES_GS_B * ncell / (kb_ms * 1e-3) / 1e9
     smooth_ms = prof["smooth"]["avg_ms"]
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -130,7 +132,7 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("size") == N and tj.get("kernel") == "k_gs_sweep":
+            if tj.get("size") == N and tj.get("kernel") == "k_gsrb_B":
                 traffic, tsrc = tj["hbm_bytes_per_launch"], tj.get("source")
         except Exception:
             pass
@@ -140,10 +142,12 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false (BASELINE configs[4] domain on 1 GPU)",
                    "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1])},
-        "roofline": {"bound": "hbm", "kernel": "k_gs_sweep<3> (finest-level red-black colour sweep, src/Poisson.jl:145)",
+        "roofline": {"bound": "hbm", "kernel": "k_gsrb_B (finest-level GaussSeidelRB!: colour sweeps 3,4 + increment!, src/Poisson.jl:141-148)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
-                     "bytes_per_cell": BYTES_GS_SWEEP, "avg_launch_ms": sweep_ms, "launches": prof["gs_sweep"]["launches"],
-                     "smooth_op": {"what": "GaussSeidelRB!(it=4) as one operation, 40 B/cell", "avg_ms": smooth_ms,
+                     "bytes_per_cell": BYTES_GS_B, "avg_launch_ms": kb_ms, "launches": prof["gsrb_B"]["launches"],
+                     "kernel_A": {"what": "k_gsrb_A: eps=r*iD + colour sweeps 1,2, 24 B/cell", "avg_ms": ka_ms,
+                                  "achieved": BYTES_GS_A * ncell / (ka_ms * 1e-3) / 1e9, "frac": BYTES_GS_A * ncell / (ka_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "smooth_op": {"what": "GaussSeidelRB!(it=4) as ONE operation (kernels A+B), 40 B/cell", "avg_ms": smooth_ms,
                                    "achieved": BYTES_SMOOTH_OP * ncell / (smooth_ms * 1e-3) / 1e9, "frac": BYTES_SMOOTH_OP * ncell / (smooth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items()},
     }

@@ -119,6 +119,8 @@ int wl_mg_level_grid(const wl_mg* mg, int level, wl_grid* out);
 /* name ∈ "L","D","iD","x","eps","r","z" — device pointer of that level's array (tests read pois.levels[k].D etc.) */
 float* wl_mg_level_field(const wl_mg* mg, int level, const char* name);
 int wl_mg_vcycle(wl_mg* mg, int level, float omega, void* stream);
+int wl_mg_smooth(wl_mg* mg, int level, int it, float omega, void* stream);      /* smooth! = GaussSeidelRB! on one level (:106) */
+int wl_mg_set_fused(wl_mg* mg, int on);   /* 1 (default): temporally blocked smoother on eligible levels; 0: one kernel per pass */
 /* solver!(ml;tol,itmx): returns iterations in *host_n and the last L₁/L∞; appends to the n history. */
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, void* stream);
 int wl_mg_history(const wl_mg* mg, int16_t* host_out, int cap);                        /* pois.n :66 */
@@ -187,9 +189,10 @@ int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm);
 /* ---- measurement hooks (bench.py): HIP-event pairs recorded on the launch stream around named launches ----
  * slots: 0 fine-level GS colour sweep (one launch), 1 fine-level smooth! (GaussSeidelRB! as a whole),
  *        2 fine-level Jacobi!, 3 conv_diff!, 4 fine-level residual!+norms, 5 BDIM!, 6 fine-level prolongate+increment,
- *        7 coarse levels (everything below level 1 of a V-cycle), 8 mom_step! as a whole                         */
+ *        7 coarse levels (everything below level 1 of a V-cycle), 8 mom_step! as a whole,
+ *        9 / 10 fine-level kernels A / B of the temporally blocked smoother (wl_fused.hip)                        */
 enum { WL_PROF_GS_SWEEP = 0, WL_PROF_SMOOTH = 1, WL_PROF_JACOBI = 2, WL_PROF_CONVDIFF = 3, WL_PROF_RESIDUAL = 4,
-       WL_PROF_BDIM = 5, WL_PROF_PROLONG = 6, WL_PROF_COARSE = 7, WL_PROF_STEP = 8, WL_PROF_NSLOTS = 9 };
+       WL_PROF_BDIM = 5, WL_PROF_PROLONG = 6, WL_PROF_COARSE = 7, WL_PROF_STEP = 8, WL_PROF_GS_A = 9, WL_PROF_GS_B = 10, WL_PROF_NSLOTS = 11 };
 int wl_prof_enable(int on);                                     /* also resets all slots */
 int wl_prof_read(int slot, int* host_count, double* host_total_ms);   /* synchronises the device */
 

@@ -223,3 +223,44 @@ def test_sphere_measure_steps_and_force(w, oracle):
         assert np.abs(sg.field("u") - so.u).max() < 5e-5
     fo, fg = so.pressure_force(), sg.pressure_force_sphere(c, R)
     assert np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+
+
+@pytest.mark.parametrize("N", [(66, 34, 18), (130, 130, 34), (34, 18, 130), (70, 45, 35), (514, 66, 20)])
+@pytest.mark.parametrize("omega", [1.0, 0.73])
+def test_fused_smoother_is_bit_identical(w, oracle, N, omega):
+    """the temporally blocked GaussSeidelRB! (two z-marching kernels, overlapped tiles, several z-chunks) against the
+    oracle AND against the one-kernel-per-pass path: ϵ, r, x bit for bit — incl. zero coefficients (iD==0), odd last
+    dimension (quirk Q4) and tiles that end exactly on the domain boundary."""
+    import ctypes as C
+    rng = np.random.default_rng(41)
+    D = 3
+    L = np.asfortranarray(rng.uniform(0.0, 1.0, size=N + (D,)).astype(np.float32))
+    L[L < 0.1] = 0
+    L[5:8, 4:7, 3:6] = 0
+    oracle.BC(L, (0,) * D)
+    x0 = np.asfortranarray(rng.uniform(-1, 1, size=N).astype(np.float32))
+    z = F(N)
+    r0 = F(N)
+    r0[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(n - 2 for n in N)).astype(np.float32)
+    try:
+        po = oracle.MultiLevelPoisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    except AssertionError:
+        po = oracle.Poisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    po.field("r", 0)[...] = r0
+    po.GaussSeidelRB(0, 4, omega)
+    lib = w.lib()
+    res = {}
+    for fused in (True, False):
+        xg, Lg, zg = w.to_device(x0), w.to_device(L), w.to_device(z)
+        pg = w.MultiLevelPoisson(xg, Lg, zg, maxlevels=2 if not hasattr(po, "multilevel") or not po.multilevel else 10) if False else None
+        try:
+            pg = w.MultiLevelPoisson(xg, Lg, zg)
+        except AssertionError:
+            pytest.skip("shape has fewer than 3 levels")
+        pg.set_fused(fused)
+        w._lib.check(lib.wl_h2d(lib.wl_mg_level_field(pg._h, 0, b"r"), r0.ctypes.data_as(C.c_void_p), r0.nbytes, w.core.stream()))
+        pg.smooth_(0, 4, omega)
+        res[fused] = (pg.levels[0].eps, pg.levels[0].r, w.to_host(xg))
+    for name, k in (("eps", 0), ("r", 1), ("x", 2)):
+        assert np.array_equal(res[True][k], res[False][k]), ("fused vs passes", name)
+        assert np.array_equal(res[True][k], po.field(name, 0)), ("fused vs oracle", name)

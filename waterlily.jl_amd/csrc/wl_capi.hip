@@ -80,7 +80,7 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
   if (grids.size() <= 2) { wl_set_error("MultiLevelPoisson requires size=a2ⁿ, where n>2"); return WL_ELEVELS; }   // :73-74
   // one slab allocation for everything the handle owns
   size_t total = 0;
-  for (size_t l = 0; l < grids.size(); l++) { const size_t nc = (size_t)wl_ncell(grids[l]); total += (l == 0 ? 4 : 4 + 2 + (size_t)grids[l].D) * nc; }
+  for (size_t l = 0; l < grids.size(); l++) { const size_t nc = (size_t)wl_ncell(grids[l]); total += (l == 0 ? 6 : 6 + 2 + (size_t)grids[l].D) * nc; }
   WL_HIP(hipMalloc((void**)&slab, total * sizeof(float)));
   WL_HIP(hipMemset(slab, 0, total * sizeof(float)));
   float* p = slab;
@@ -88,7 +88,7 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
   for (size_t l = 0; l < grids.size(); l++) {
     Level& v = lv[l]; v.g = grids[l]; v.x_ = gx(grids[l]); v.dist = isdist[l]; v.has_view = hasview[l]; v.view = gx(views[l]);
     const size_t nc = (size_t)wl_ncell(grids[l]);
-    v.r = p; p += nc; v.eps = p; p += nc; v.D = p; p += nc; v.iD = p; p += nc;
+    v.r = p; p += nc; v.eps = p; p += nc; v.D = p; p += nc; v.iD = p; p += nc; v.em = p; p += nc; v.rs = p; p += nc;
     if (l == 0) { v.x = x; v.L = L; v.z = z; }
     else { v.L = p; p += nc * (size_t)grids[l].D; v.x = p; p += nc; v.z = p; p += nc; }
   }
@@ -124,6 +124,12 @@ int wl_mg::update(hipStream_t s) {                                              
 int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
   Level& p = lv[(size_t)l];
   ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
+  if (it == 4 && use_fused && wl::gsrb_fused_ok(p.x_, perdir, p.dist)) {   // two z-marching kernels instead of six passes
+    { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.iD, p.x_, s)); }
+    { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(p.eps, p.rs, p.x, p.em, p.r, p.L, p.D, p.iD, p.x_, w, s)); }
+    std::swap(p.r, p.rs);
+    return 0;
+  }
   const bool fuse = !perdir && !p.dist && it >= 1;   // ghost ϵ are plain memory reads only on these levels
   if (fuse) WL_TRY(wl::gs_init_sweep1(p.eps, p.r, p.L, p.iD, p.x_, s));
   else {
@@ -345,6 +351,8 @@ float* wl_mg_level_field(const wl_mg* mg, int l, const char* name) {
   if (s == "eps") return v.eps; if (s == "r") return v.r; if (s == "z") return v.z;
   return nullptr;
 }
+int wl_mg_smooth(wl_mg* mg, int l, int it, float w, void* st) { WL_CHECK(l >= 0 && l < (int)mg->lv.size(), "level out of range"); return mg->smooth(l, it <= 0 ? 4 : it, w, wl_stream(st)); }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = on != 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st)); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

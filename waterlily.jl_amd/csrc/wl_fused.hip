@@ -1,0 +1,200 @@
+// Temporally blocked red–black Gauss–Seidel for gfx950: GaussSeidelRB!(it=4) (src/Poisson.jl:141-148) in TWO
+// z-marching kernels instead of six passes over HBM.
+//   kernel A:  ϵ = r·iD ; colour sweep 1 ; colour sweep 2                 R r,iD,L (20 B/cell)            W ϵ_mid (4)
+//   kernel B:  colour sweep 3 ; colour sweep 4 ; increment!(ω)            R ϵ_mid,r,iD,L,D,x (32)         W ϵ,r',x (12)
+// A workgroup owns an x-y tile of 64×16 threads (one cell column per thread) and marches along z.  Each stage lags
+// the previous one by one plane, so a cell's z-neighbours are the thread's own registers; x-y neighbours come from LDS
+// (two or three double-buffered 64×16 planes).  Tiles overlap by the dependency depth (2 resp. 3 cells per side): halo
+// threads recompute their neighbours' values instead of waiting for them, and results are taken from the tile core
+// only.  Because halo threads read inputs that the owning tile also updates, outputs never alias inputs: ϵ_mid, ϵ and
+// r' are separate arrays (the handle swaps r↔r' afterwards); x is read and written by its owner only.
+// Arithmetic (operation order, colour rule, quirk Q4) is exactly that of k_gs_sweep/k_increment ⇒ bit-identical results.
+// Preconditions (checked by the caller): D==3, non-periodic, not a z-slab level, ghost cells of r, iD, ϵ are zero
+// (true for the arrays a wl_mg handle owns), so `r·iD` of a ghost cell reproduces the stored ghost ϵ (=0).
+#include "wl_common.hpp"
+
+#define ZT_X 64
+#define ZT_Y 16
+#define ZT_N (ZT_X * ZT_Y)
+#define ZT_LDS ((ZT_Y + 2) * ZT_X)   // one guard row above and below: neighbour indices never leave the array
+
+namespace {
+
+struct ZTile {
+  int i, j;        // global cell column of this thread
+  int li;          // LDS index of this thread
+  bool indom;      // column exists (0 <= i < nx, 0 <= j < ny)
+  bool inter;      // interior column (may be updated)
+  bool core;       // this thread's results are stored (inside the tile core and interior)
+  long oc;         // i + j*sy
+  int ks, ke;      // output planes [ks,ke) of this workgroup
+  bool alive;      // tile exists
+};
+
+template <int H>
+__device__ __forceinline__ ZTile ztile(const GridX& g, int zchunk) {
+  ZTile t;
+  const int CX = ZT_X - 2 * H, CY = ZT_Y - 2 * H;
+  const int ntx = (g.nx - 2 + CX - 1) / CX, nty = (g.ny - 2 + CY - 1) / CY;
+  const int ntiles = ntx * nty;
+  const unsigned h = blockIdx.x, q = h & 7u, s = h >> 3;
+  const unsigned per = (unsigned)((ntiles + 7) >> 3);      // XCD q walks a contiguous range of tiles
+  const int c = (int)(s / per);
+  const int tl = (int)(q * per + (s - (unsigned)c * per));
+  t.alive = tl < ntiles;
+  const int tx = tl % ntx, ty = tl / ntx;
+  const int lx = threadIdx.x & (ZT_X - 1), ly = threadIdx.x >> 6;
+  t.i = 1 + tx * CX - H + lx;
+  t.j = 1 + ty * CY - H + ly;
+  t.li = ZT_X + lx + ly * ZT_X;
+  t.indom = t.i >= 0 && t.i < g.nx && t.j >= 0 && t.j < g.ny;
+  t.inter = t.i >= 1 && t.i <= g.nx - 2 && t.j >= 1 && t.j <= g.ny - 2;
+  t.core = t.inter && lx >= H && lx < ZT_X - H && ly >= H && ly < ZT_Y - H;
+  t.oc = (long)t.i + (long)t.j * g.sy;
+  t.ks = g.k0 + c * zchunk;
+  t.ke = t.ks + zchunk < g.k1 ? t.ks + zchunk : g.k1;
+  return t;
+}
+__host__ __device__ inline int ztile_count(int nx, int ny, int H) {
+  const int CX = ZT_X - 2 * H, CY = ZT_Y - 2 * H;
+  return ((nx - 2 + CX - 1) / CX) * ((ny - 2 + CY - 1) / CY);
+}
+// may the cell (i,j,K) be updated by colour sweep k0?  colour rule + quirk Q4 exactly as k_gs_sweep (D==3)
+__device__ __forceinline__ bool gs_upd(const GridX& g, int i, int j, int K, int k0) {
+  return (((i + j + K + 3 + k0) & 1) != 0) && !(K + 1 > 2 * (g.gnz / 2) - 1);
+}
+// gauss(I,r,L,iD,ϵ)  src/Poisson.jl:116-122, with the neighbours handed in
+__device__ __forceinline__ float gs_val(float r, float iD, float exm, float exp_, float eym, float eyp, float ezm, float ezp, float lx, float lxp, float ly, float lyp, float lz, float lzp) {
+  float s = r;
+  s -= (exm * lx + exp_ * lxp);
+  s -= (eym * ly + eyp * lyp);
+  s -= (ezm * lz + ezp * lzp);
+  return s * iD;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernel A
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ZT_N) k_gsrb_A(GridX g, float* __restrict__ emid, const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ iD, int zchunk) {
+  __shared__ float sA[2][ZT_LDS];   // ϵ⁰ of the newest plane           (x-y neighbours of sweep 1 one step later)
+  __shared__ float sB[2][ZT_LDS];   // ϵ after sweep 1 of plane K-1     (x-y neighbours of sweep 2 one step later)
+  const ZTile t = ztile<2>(g, zchunk);
+  if (!t.alive) return;
+  for (int q = threadIdx.x; q < ZT_LDS; q += ZT_N) { sA[0][q] = 0.f; sA[1][q] = 0.f; sB[0][q] = 0.f; sB[1][q] = 0.f; }
+  const float* __restrict__ Lx = L; const float* __restrict__ Ly = L + g.cs; const float* __restrict__ Lz = L + 2 * g.cs;
+  // rolling registers; index 0 = plane K, 1 = K-1, 2 = K-2, 3 = K-3
+  float e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+  float r0 = 0, r1 = 0, r2 = 0, d0 = 0, d1 = 0, d2 = 0, lz0 = 0, lz1 = 0, lz2 = 0;
+  float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0;
+  const int Kbeg = t.ks - 2, Kend = t.ke + 1;     // planes whose ϵ⁰ is needed
+  for (int K = Kbeg; K <= Kend; K++) {
+    // ---- shift the pipeline
+    e3 = e2; e2 = e1; e1 = e0; r2 = r1; r1 = r0; d2 = d1; d1 = d0; lz2 = lz1; lz1 = lz0;
+    lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1;
+    // ---- load plane K (r, iD, Lz) and the in-plane coefficients of plane K-1
+    const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
+    const long o0 = t.oc + (long)K * g.sz;
+    r0 = pl0 ? r[o0] : 0.f; d0 = pl0 ? iD[o0] : 0.f; lz0 = pl0 ? Lz[o0] : 0.f;
+    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const long o1 = o0 - g.sz;
+    lx1 = pl1 ? Lx[o1] : 0.f; lxp1 = pl1 ? Lx[o1 + 1] : 0.f; ly1 = pl1 ? Ly[o1] : 0.f; lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+    e0 = r0 * d0;                                                   // ϵ = r·iD   :142 (ghost cells: 0·0)
+    __syncthreads();                                                // LDS of the previous step is complete
+    const int pb = (K - 1) & 1, cb = K & 1;
+    // ---- sweep 1 on plane K-1 (its x-y neighbours: ϵ⁰ written one step ago)
+    if (pl1 && (K - 1) >= t.ks - 1 && gs_upd(g, t.i, t.j, g.gk + K - 1, 1))
+      e1 = gs_val(r1, d1, sA[pb][t.li - 1], sA[pb][t.li + 1], sA[pb][t.li - ZT_X], sA[pb][t.li + ZT_X], e2, e0, lx1, lxp1, ly1, lyp1, lz1, lz0);
+    // ---- sweep 2 on plane K-2 (x-y neighbours: plane K-2 after sweep 1, written one step ago)
+    const bool pl2 = t.inter && (K - 2) >= g.k0 && (K - 2) < g.k1;
+    if (pl2 && (K - 2) >= t.ks && gs_upd(g, t.i, t.j, g.gk + K - 2, 2))
+      e2 = gs_val(r2, d2, sB[pb][t.li - 1], sB[pb][t.li + 1], sB[pb][t.li - ZT_X], sB[pb][t.li + ZT_X], e3, e1, lx2, lxp2, ly2, lyp2, lz2, lz1);
+    sA[cb][t.li] = e0;
+    sB[cb][t.li] = e1;
+    if (t.core && (K - 2) >= t.ks && (K - 2) < t.ke) emid[o0 - 2 * g.sz] = e2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernel B
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(ZT_N) k_gsrb_B(GridX g, float* __restrict__ eout, float* __restrict__ rout, float* __restrict__ x, const float* __restrict__ emid,
+                                                 const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float w, int zchunk) {
+  __shared__ float sA[2][ZT_LDS];   // ϵ_mid of the newest plane                 (neighbours of sweep 3 one step later)
+  __shared__ float sB[2][ZT_LDS];   // plane K-1 after sweep 3                   (neighbours of sweep 4 one step later)
+  __shared__ float sC[2][ZT_LDS];   // plane K-2 after sweep 4 = final ϵ         (neighbours of increment! one step later)
+  const ZTile t = ztile<3>(g, zchunk);
+  if (!t.alive) return;
+  for (int q = threadIdx.x; q < ZT_LDS; q += ZT_N) { sA[0][q] = 0.f; sA[1][q] = 0.f; sB[0][q] = 0.f; sB[1][q] = 0.f; sC[0][q] = 0.f; sC[1][q] = 0.f; }
+  const float* __restrict__ Lx = L; const float* __restrict__ Ly = L + g.cs; const float* __restrict__ Lz = L + 2 * g.cs;
+  float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;                     // planes K .. K-4
+  float r1 = 0, r2 = 0, r3 = 0, d1 = 0, d2 = 0, lz0 = 0, lz1 = 0, lz2 = 0, lz3 = 0;
+  float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0, lx3 = 0, lxp3 = 0, ly3 = 0, lyp3 = 0;
+  const int Kbeg = t.ks - 3, Kend = t.ke + 2;
+  for (int K = Kbeg; K <= Kend; K++) {
+    e4 = e3; e3 = e2; e2 = e1; e1 = e0; r3 = r2; r2 = r1; d2 = d1; lz3 = lz2; lz2 = lz1; lz1 = lz0;
+    lx3 = lx2; lxp3 = lxp2; ly3 = ly2; lyp3 = lyp2; lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1;
+    const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
+    const long o0 = t.oc + (long)K * g.sz;
+    e0 = pl0 ? emid[o0] : 0.f; lz0 = pl0 ? Lz[o0] : 0.f;
+    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const long o1 = o0 - g.sz;
+    r1 = pl1 ? r[o1] : 0.f; d1 = pl1 ? iD[o1] : 0.f;
+    lx1 = pl1 ? Lx[o1] : 0.f; lxp1 = pl1 ? Lx[o1 + 1] : 0.f; ly1 = pl1 ? Ly[o1] : 0.f; lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+    // increment! operands of plane K-3 (issued early, used at the end of the step)
+    const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
+    const long o3 = o0 - 3 * g.sz;
+    const float dg3 = pl3 ? Dg[o3] : 0.f, x3 = pl3 ? x[o3] : 0.f;
+    __syncthreads();
+    const int pb = (K - 1) & 1, cb = K & 1;
+    // ---- sweep 3 on plane K-1
+    if (pl1 && (K - 1) >= t.ks - 2 && gs_upd(g, t.i, t.j, g.gk + K - 1, 3))
+      e1 = gs_val(r1, d1, sA[pb][t.li - 1], sA[pb][t.li + 1], sA[pb][t.li - ZT_X], sA[pb][t.li + ZT_X], e2, e0, lx1, lxp1, ly1, lyp1, lz1, lz0);
+    // ---- sweep 4 on plane K-2
+    const bool pl2 = t.inter && (K - 2) >= g.k0 && (K - 2) < g.k1;
+    if (pl2 && (K - 2) >= t.ks - 1 && gs_upd(g, t.i, t.j, g.gk + K - 2, 4))
+      e2 = gs_val(r2, d2, sB[pb][t.li - 1], sB[pb][t.li + 1], sB[pb][t.li - ZT_X], sB[pb][t.li + ZT_X], e3, e1, lx2, lxp2, ly2, lyp2, lz2, lz1);
+    // ---- increment! on plane K-3: r' = r − ω·Aϵ ; x += ω·ϵ          src/Poisson.jl:100-104, mult :70-76
+    if (pl3) {
+      float s = e3 * dg3;
+      s += (sC[pb][t.li - 1] * lx3 + sC[pb][t.li + 1] * lxp3);
+      s += (sC[pb][t.li - ZT_X] * ly3 + sC[pb][t.li + ZT_X] * lyp3);
+      s += (e4 * lz3 + e2 * lz2);
+      rout[o3] = r3 - w * s;
+      x[o3] = x3 + w * e3;
+      eout[o3] = e3;
+    }
+    sA[cb][t.li] = e0;
+    sB[cb][t.li] = e1;
+    sC[cb][t.li] = e2;
+  }
+}
+}  // namespace
+
+namespace wl {
+// Eligibility of a level for the fused smoother
+bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist) {
+  return g.D == 3 && per == 0 && !dist && g.nz == g.gnz && g.nx >= 34 && g.ny >= 18 && (g.k1 - g.k0) >= 8;
+}
+static int zchunk_for(const GridX& g, int H) {
+  // enough workgroups to fill 256 CUs a few times over, but long marches (the pipeline warm-up costs 2H planes per chunk)
+  const int nt = ztile_count(g.nx, g.ny, H);
+  const int np = g.k1 - g.k0;
+  int chunks = (1536 + nt - 1) / nt; if (chunks < 1) chunks = 1;
+  int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
+  return zc;
+}
+// GaussSeidelRB!(it=4,ω): emid and rout are scratch arrays of the level (ghosts zero); on return eps holds the final ϵ,
+// rout the new residual (caller swaps r<->rout) and x is updated in place.
+int gsrb_fused_A(float* emid, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s) {
+  const int zc = zchunk_for(g, 2);
+  const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
+  hipLaunchKernelGGL(k_gsrb_A, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, r, L, iD, zc);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const float* Dg, const float* iD, const GridX& g, float w, hipStream_t s) {
+  const int zc = zchunk_for(g, 3);
+  const int nt = ztile_count(g.nx, g.ny, 3), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
+  hipLaunchKernelGGL(k_gsrb_B, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, eps, rout, x, emid, r, L, Dg, iD, w, zc);
+  WL_LAUNCH_CHECK(); return 0;
+}
+}  // namespace wl

@@ -8,6 +8,7 @@ struct wl_mg {
   struct Level {            // one `Poisson` (src/Poisson.jl:22-39)
     wl_grid g; GridX x_;
     float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
+    float *em = nullptr, *rs = nullptr;   // scratch of the fused smoother: ϵ after sweep 2, new residual (ghosts stay zero)
     bool dist = false;       // z-slab distributed level (halo exchanges) vs replicated on every rank
     GridX view;              // replicated level fed by a distributed parent: the planes of the full array this rank computes
     bool has_view = false;
@@ -16,6 +17,7 @@ struct wl_mg {
   std::vector<Level> lv;
   std::vector<int16_t> n;   // pois.n :66
   unsigned perdir = 0;
+  bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
   float* slab = nullptr;    // owns r,ϵ,D,iD of every level and L,x,z of the coarse levels
   void* red = nullptr;      // reduction workspace
   RedWs ws;

@@ -167,6 +167,13 @@ class MultiLevelPoisson:
         """Vcycle!(ml;l,ω)   :88-101 (l is 0-based here)"""
         check(lib().wl_mg_vcycle(self._h, int(l), float(w), stream()))
 
+    def smooth_(self, l=0, it=4, w=1.0):
+        """smooth!(levels[l];ω) = GaussSeidelRB!   src/MultiLevelPoisson.jl:106"""
+        check(lib().wl_mg_smooth(self._h, int(l), int(it), float(w), stream()))
+
+    def set_fused(self, on):
+        check(lib().wl_mg_set_fused(self._h, int(bool(on))))
+
     def solver_(self, tol=2e-3, itmx=32):
         """solver!(ml;tol,itmx)   :108-128"""
         n, r1, rinf = C.c_int(), C.c_double(), C.c_float()
