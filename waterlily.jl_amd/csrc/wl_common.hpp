@@ -173,6 +173,8 @@ int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStre
 int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per, hipStream_t s);
 int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
+int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
+                   float dt, float pre, float post, hipStream_t s);
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s);
 int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s);
 int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s);

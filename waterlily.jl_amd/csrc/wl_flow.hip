@@ -121,8 +121,11 @@ __device__ __forceinline__ float face_flux(float U, float t0, float t1, float t2
   return U * X - nu * (fc - fm);
 }
 // PER = 0: no periodic direction (no wrapped addresses, no branches at all); IDX = int when every component offset fits 31 bits
-template <int D, int SCH, int PER, typename IDX>
-__global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst) {
+// FUSE = 1 appends BDIM! for the NoBody case (μ₁≡0, V≡0; src/Flow.jl:176-180 + the folded scale_u!):
+//   f = u⁰ + Δt·r (all cells) ; u_out = (u·pre + μ₀·f)·post (interior).  u_out must not alias the advecting field u.
+struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre, post; int scale_after; };
+template <int D, int SCH, int PER, typename IDX, int FUSE>
+__global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst, BdimArgs bd) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
@@ -170,6 +173,23 @@ __global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restri
       acc = con ? acc - Pu : acc;
     }
     out[a] = acc;
+  }
+  if (FUSE) {
+    bool in = interior_ij(g, i, j);
+    if (D == 3) in = in && k >= g.k0 && k < g.k1;
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+      const long oa = (long)a * g.cs + o;
+      const float fn = bd.u0[oa] + bd.dt * out[a] - 0.f;
+      r[oa] = fn;
+      if (in) {
+        const float xx = (0.f / 2 + 0.f) + bd.mu0[oa] * fn;
+        float un = (bd.pre == 0.f) ? xx : (u[oa] * bd.pre + xx);
+        if (bd.scale_after) un = un * bd.post;
+        bd.uout[oa] = un;
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int a = 0; a < D; a++) r[(long)a * g.cs + o] = out[a];
@@ -484,19 +504,18 @@ int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s) {
 }
 
 template <int D, int SCH>
-static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s) {
+static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s, const BdimArgs* bd) {
   // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   const dim3 grid = wl_plane_grid(g, klast - kfirst);
   const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
-  if (per) {
-    if (small) hipLaunchKernelGGL((k_conv_diff<D, SCH, 1, int>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
-    else hipLaunchKernelGGL((k_conv_diff<D, SCH, 1, long>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
-  } else {
-    if (small) hipLaunchKernelGGL((k_conv_diff<D, SCH, 0, int>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
-    else hipLaunchKernelGGL((k_conv_diff<D, SCH, 0, long>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst);
-  }
+  BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0};
+  const BdimArgs ba = bd ? *bd : b0;
+#define WL_CD(PERF, IDXT, FUSEF) hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba)
+  if (bd) { if (per) { if (small) WL_CD(1, int, 1); else WL_CD(1, long, 1); } else { if (small) WL_CD(0, int, 1); else WL_CD(0, long, 1); } }
+  else    { if (per) { if (small) WL_CD(1, int, 0); else WL_CD(1, long, 0); } else { if (small) WL_CD(0, int, 0); else WL_CD(0, long, 0); } }
+#undef WL_CD
   if (Phi) {
     long cmax = (long)g.ny * (D == 3 ? g.nz : 1);
     cmax = cmax > (long)g.nx * (D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (D == 3 ? g.nz : 1);
@@ -506,16 +525,23 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   WL_LAUNCH_CHECK(); return 0;
 }
 template <int D>
-static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
+static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s, const BdimArgs* bd) {
   switch (scheme) {
-    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s);
-    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s);
-    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s);
+    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s, bd);
+    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s, bd);
+    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s, bd);
   }
   wl_set_error("unknown scheme"); return WL_EINVAL;
 }
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
-  return g.D == 3 ? conv_diff_launch<3>(r, u, Phi, g, nu, per, scheme, s) : conv_diff_launch<2>(r, u, Phi, g, nu, per, scheme, s);
+  return g.D == 3 ? conv_diff_launch<3>(r, u, Phi, g, nu, per, scheme, s, nullptr) : conv_diff_launch<2>(r, u, Phi, g, nu, per, scheme, s, nullptr);
+}
+// conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: f and u_out written, u_out must not alias u_adv
+int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
+                   float dt, float pre, float post, hipStream_t s) {
+  if (u_out == u_adv) { wl_set_error("conv_diff_bdim: output aliases the advecting field"); return WL_EINVAL; }
+  BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0};
+  return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
 }
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s) {
   const int scale_after = (post != 1.f) ? 1 : 0;

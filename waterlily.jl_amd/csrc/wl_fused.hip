@@ -87,17 +87,25 @@ __global__ void __launch_bounds__(ZT_N) k_gsrb_A(GridX g, float* __restrict__ em
   float r0 = 0, r1 = 0, r2 = 0, d0 = 0, d1 = 0, d2 = 0, lz0 = 0, lz1 = 0, lz2 = 0;
   float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0;
   const int Kbeg = t.ks - 2, Kend = t.ke + 1;     // planes whose ϵ⁰ is needed
+  // operands of the NEXT step are fetched one plane ahead so that their latency overlaps this step's barrier and arithmetic
+  float n_r0, n_d0, n_lz0, n_lx1, n_lxp1, n_ly1, n_lyp1;
+  auto fetch = [&](int K) {
+    const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
+    const long o0 = t.oc + (long)K * g.sz;
+    n_r0 = pl0 ? r[o0] : 0.f; n_d0 = pl0 ? iD[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
+    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const long o1 = o0 - g.sz;
+    n_lx1 = pl1 ? Lx[o1] : 0.f; n_lxp1 = pl1 ? Lx[o1 + 1] : 0.f; n_ly1 = pl1 ? Ly[o1] : 0.f; n_lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+  };
+  fetch(Kbeg);
   for (int K = Kbeg; K <= Kend; K++) {
     // ---- shift the pipeline
     e3 = e2; e2 = e1; e1 = e0; r2 = r1; r1 = r0; d2 = d1; d1 = d0; lz2 = lz1; lz1 = lz0;
     lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1;
-    // ---- load plane K (r, iD, Lz) and the in-plane coefficients of plane K-1
-    const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
-    const long o0 = t.oc + (long)K * g.sz;
-    r0 = pl0 ? r[o0] : 0.f; d0 = pl0 ? iD[o0] : 0.f; lz0 = pl0 ? Lz[o0] : 0.f;
+    r0 = n_r0; d0 = n_d0; lz0 = n_lz0; lx1 = n_lx1; lxp1 = n_lxp1; ly1 = n_ly1; lyp1 = n_lyp1;
+    if (K < Kend) fetch(K + 1);
     const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
-    const long o1 = o0 - g.sz;
-    lx1 = pl1 ? Lx[o1] : 0.f; lxp1 = pl1 ? Lx[o1 + 1] : 0.f; ly1 = pl1 ? Ly[o1] : 0.f; lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+    const long o0 = t.oc + (long)K * g.sz;
     e0 = r0 * d0;                                                   // ϵ = r·iD   :142 (ghost cells: 0·0)
     __syncthreads();                                                // LDS of the previous step is complete
     const int pb = (K - 1) & 1, cb = K & 1;
@@ -130,20 +138,29 @@ __global__ void __launch_bounds__(ZT_N) k_gsrb_B(GridX g, float* __restrict__ eo
   float r1 = 0, r2 = 0, r3 = 0, d1 = 0, d2 = 0, lz0 = 0, lz1 = 0, lz2 = 0, lz3 = 0;
   float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0, lx3 = 0, lxp3 = 0, ly3 = 0, lyp3 = 0;
   const int Kbeg = t.ks - 3, Kend = t.ke + 2;
+  float n_e0, n_lz0, n_r1, n_d1, n_lx1, n_lxp1, n_ly1, n_lyp1, n_dg3, n_x3;
+  auto fetch = [&](int K) {
+    const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
+    const long o0 = t.oc + (long)K * g.sz;
+    n_e0 = pl0 ? emid[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
+    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const long o1 = o0 - g.sz;
+    n_r1 = pl1 ? r[o1] : 0.f; n_d1 = pl1 ? iD[o1] : 0.f;
+    n_lx1 = pl1 ? Lx[o1] : 0.f; n_lxp1 = pl1 ? Lx[o1 + 1] : 0.f; n_ly1 = pl1 ? Ly[o1] : 0.f; n_lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+    const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
+    const long o3 = o0 - 3 * g.sz;
+    n_dg3 = pl3 ? Dg[o3] : 0.f; n_x3 = pl3 ? x[o3] : 0.f;
+  };
+  fetch(Kbeg);
   for (int K = Kbeg; K <= Kend; K++) {
     e4 = e3; e3 = e2; e2 = e1; e1 = e0; r3 = r2; r2 = r1; d2 = d1; lz3 = lz2; lz2 = lz1; lz1 = lz0;
     lx3 = lx2; lxp3 = lxp2; ly3 = ly2; lyp3 = lyp2; lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1;
-    const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
-    const long o0 = t.oc + (long)K * g.sz;
-    e0 = pl0 ? emid[o0] : 0.f; lz0 = pl0 ? Lz[o0] : 0.f;
+    e0 = n_e0; lz0 = n_lz0; r1 = n_r1; d1 = n_d1; lx1 = n_lx1; lxp1 = n_lxp1; ly1 = n_ly1; lyp1 = n_lyp1;
+    const float dg3 = n_dg3, x3 = n_x3;
+    if (K < Kend) fetch(K + 1);
     const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
-    const long o1 = o0 - g.sz;
-    r1 = pl1 ? r[o1] : 0.f; d1 = pl1 ? iD[o1] : 0.f;
-    lx1 = pl1 ? Lx[o1] : 0.f; lxp1 = pl1 ? Lx[o1 + 1] : 0.f; ly1 = pl1 ? Ly[o1] : 0.f; lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
-    // increment! operands of plane K-3 (issued early, used at the end of the step)
     const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
-    const long o3 = o0 - 3 * g.sz;
-    const float dg3 = pl3 ? Dg[o3] : 0.f, x3 = pl3 ? x[o3] : 0.f;
+    const long o3 = t.oc + (long)(K - 3) * g.sz;
     __syncthreads();
     const int pb = (K - 1) & 1, cb = K & 1;
     // ---- sweep 3 on plane K-1

@@ -182,11 +182,11 @@ __global__ void k_gs_init_sweep1(GridX g, float* __restrict__ eps, const float* 
   bool upd = ((i + j + K + D + 1) & 1) != 0;                                    // colour of sweep k₀=1
   if (D == 3) upd = upd && !(K + 1 > 2 * (g.gnz / 2) - 1); else upd = upd && !(j + 1 > 2 * (g.ny / 2) - 1);   // quirk Q4
   if (!upd) { eps[o] = e0; return; }
-  auto E = [&](long oo, bool in) -> float { return in ? r[oo] * iD[oo] : eps[oo]; };
+  auto E = [&](long oo) -> float { return r[oo] * iD[oo]; };      // ghosts: 0·0 = the stored ghost ϵ (handle-owned arrays)
   float s = r[o];
-  s -= (E(o - 1, i > 1) * L[o] + E(o + 1, i < g.nx - 2) * L[o + 1]);
-  s -= (E(o - g.sy, j > 1) * L[g.cs + o] + E(o + g.sy, j < g.ny - 2) * L[g.cs + o + g.sy]);
-  if (D == 3) s -= (E(o - g.sz, k > g.k0) * L[2 * g.cs + o] + E(o + g.sz, k < g.k1 - 1) * L[2 * g.cs + o + g.sz]);
+  s -= (E(o - 1) * L[o] + E(o + 1) * L[o + 1]);
+  s -= (E(o - g.sy) * L[g.cs + o] + E(o + g.sy) * L[g.cs + o + g.sy]);
+  if (D == 3) s -= (E(o - g.sz) * L[2 * g.cs + o] + E(o + g.sz) * L[2 * g.cs + o + g.sz]);
   eps[o] = s * iD[o];
 }
 // Jacobi!(it=1,ω): ϵ=r·iD ; r -= ωAϵ ; x += ωϵ in ONE pass.  The new residual goes to `rout` (≠ r: neighbours still read
@@ -199,13 +199,13 @@ __global__ void k_jacobi_pp(GridX g, float* __restrict__ rout, const float* __re
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
   const int k = g.k0 + pz;
   const long o = m + (long)k * g.sz;
-  // rout's ghost cells hold the (zero) ghosts of the buffer that used to be ϵ: both are zero on these levels
-  auto E = [&](long oo, bool in) -> float { return in ? r[oo] * iD[oo] : rout[oo]; };
+  // ghost cells of r, iD and ϵ are zero in the arrays a wl_mg handle owns, so r·iD of a ghost reproduces its stored ϵ (=0)
+  auto E = [&](long oo) -> float { return r[oo] * iD[oo]; };
   const float e0 = r[o] * iD[o];
   float s = e0 * Dg[o];
-  s += (E(o - 1, i > 1) * L[o] + E(o + 1, i < g.nx - 2) * L[o + 1]);
-  s += (E(o - g.sy, j > 1) * L[g.cs + o] + E(o + g.sy, j < g.ny - 2) * L[g.cs + o + g.sy]);
-  if (D == 3) s += (E(o - g.sz, k > g.k0) * L[2 * g.cs + o] + E(o + g.sz, k < g.k1 - 1) * L[2 * g.cs + o + g.sz]);
+  s += (E(o - 1) * L[o] + E(o + 1) * L[o + 1]);
+  s += (E(o - g.sy) * L[g.cs + o] + E(o + g.sy) * L[g.cs + o + g.sy]);
+  if (D == 3) s += (E(o - g.sz) * L[2 * g.cs + o] + E(o + g.sz) * L[2 * g.cs + o + g.sz]);
   rout[o] = r[o] - w * s;
   x[o] = x[o] + w * e0;
 }
@@ -274,11 +274,8 @@ __global__ void k_prolong_increment(GridX gf, GridX gc, float* __restrict__ r, f
   if (!cell_ij(gf, m, i, j) || !interior_ij(gf, i, j)) return;
   const int k = gf.k0 + pz;
   const long o = m + (long)k * gf.sz;
-  auto E = [&](int ii, int jj, int kk, long oo) -> float {
-    bool in = ii >= 1 && ii <= gf.nx - 2 && jj >= 1 && jj <= gf.ny - 2;
-    if (D == 3) { const int K = gf.gk + kk; in = in && K >= 1 && K <= gf.gnz - 2; }
-    return in ? xc[down_off<D>(gf, gc, ii, jj, kk, cx, cy, cz)] : eps[oo];
-  };
+  // a fine ghost cell maps onto a coarse ghost cell; both hold zero in handle-owned arrays, so no predicate is needed
+  auto E = [&](int ii, int jj, int kk, long) -> float { return xc[down_off<D>(gf, gc, ii, jj, kk, cx, cy, cz)]; };
   const float e0 = xc[down_off<D>(gf, gc, i, j, k, cx, cy, cz)];
   float s = e0 * Dg[o];
   s += (E(i - 1, j, k, o - 1) * L[o] + E(i + 1, j, k, o + 1) * L[o + 1]);

@@ -187,6 +187,7 @@ struct wl_sim {
   wl_mg* mg = nullptr;
   wl_comm* comm = nullptr;   // not owned; NULL for a single domain
   bool swap_ok = false;      // u and u⁰ are handle-owned and every ghost of u is rewritten by BC! (no exitBC)
+  float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
   ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
 
@@ -203,13 +204,24 @@ struct wl_sim {
   }
   int exit_bc(hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
-    { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
-    WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
+    if (us && !d.has_body) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
+      ProfScope pc(WL_PROF_CONVDIFF, s);
+      WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, s));
+    } else {
+      { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
+      WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
+    }
     WL_TRY(bc_u(s));
     if (d.exitBC) WL_TRY(exit_bc(s));
     return 0;
   }
   int correct(hipStream_t s) {                                                           // mom_correct! :205-210
+    if (us && !d.has_body) {   // the advecting field is u itself: write the new u to the spare array and swap
+      { ProfScope pc(WL_PROF_CONVDIFF, s);
+        WL_TRY(wl::conv_diff_bdim(f, u, sigma, u0, mu0, us, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 1.f, 0.5f, s)); }
+      std::swap(u, us);
+      return bc_u(s);
+    }
     { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
     WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
@@ -297,6 +309,8 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   float* given[8] = {desc->u, desc->u0, desc->f, desc->p, desc->sigma, desc->V, desc->mu0, desc->mu1};
   const size_t sz[8] = {nc * D, nc * D, nc * D, nc, nc, nc * D, nc * D, nc * D * D};
   size_t total = 0;
+  const bool want_us = !desc->u && !desc->u0 && !desc->exitBC && !desc->has_body;
+  if (want_us) total += nc * D;
   for (int q = 0; q < 8; q++) if (!given[q] && !(q == 7 && !desc->has_body) && !(q == 5 && !desc->has_body)) total += sz[q];
   if (total) { hipError_t e = hipMalloc((void**)&s->own, total * sizeof(float)); if (e != hipSuccess) { delete s; wl_set_error("hipMalloc failed for flow arrays"); return (int)e; } (void)hipMemset(s->own, 0, total * sizeof(float)); }
   float* pcur = s->own;
@@ -305,6 +319,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     else if ((q == 7 || q == 5) && !desc->has_body) *ptrs[q] = nullptr;
     else { *ptrs[q] = pcur; pcur += sz[q]; }
   }
+  if (want_us) { s->us = pcur; pcur += nc * D; }
   s->dt.assign(1, desc->dt0);
   s->swap_ok = !desc->u && !desc->u0 && !desc->exitBC;
   // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
