@@ -147,6 +147,8 @@ float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sig
 wl_mg* wl_sim_pois(wl_sim* s);
 int wl_sim_grid(const wl_sim* s, wl_grid* out);
 int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀ BC, (src/Flow.jl:141-145) after the caller filled u */
+/* implementation switches (tests compare the variants): "convz" (z-marching conv_diff!), "fused_smoother" — default 1 */
+int wl_sim_set_option(wl_sim* s, const char* name, int value);
 int wl_sim_update(wl_sim* s, void* stream);             /* update!(pois) after μ₀ changed (measure!, src/WaterLily.jl:148) */
 int wl_sim_mom_step(wl_sim* s, void* stream);           /* mom_step!(flow,pois): appends Δt */
 int wl_sim_dt(const wl_sim* s, float* host_out, int cap);      /* flow.Δt (host vector, src/Flow.jl:127) */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "wl_sim_pois": (P, [P]),
     "wl_sim_grid": (i32, [P, G]),
     "wl_sim_init_flow": (i32, [P, P]),
+    "wl_sim_set_option": (i32, [P, C.c_char_p, i32]),
     "wl_sim_update": (i32, [P, P]),
     "wl_sim_mom_step": (i32, [P, P]),
     "wl_sim_dt": (i32, [P, C.POINTER(f32), i32]),

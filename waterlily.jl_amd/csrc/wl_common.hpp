@@ -175,6 +175,9 @@ int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
                    float dt, float pre, float post, hipStream_t s);
+int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
+bool conv_z_ok(const GridX& g, unsigned per);
+int conv_diff_z(float* f, const float* u_adv, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, int scheme, float dt, float pre, float post, hipStream_t s);
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s);
 int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s);
 int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s);

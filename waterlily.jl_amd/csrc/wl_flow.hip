@@ -536,6 +536,19 @@ static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
   return g.D == 3 ? conv_diff_launch<3>(r, u, Phi, g, nu, per, scheme, s, nullptr) : conv_diff_launch<2>(r, u, Phi, g, nu, per, scheme, s, nullptr);
 }
+// quirk Q1 alone: the stale ghost-plane fluxes conv_diff! leaves in Φ≡σ (used with the z-marching kernel)
+int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s) {
+  if (!Phi) return 0;
+  long cmax = (long)g.ny * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > (long)g.nx * (g.D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > g.sz ? cmax : g.sz;
+  const dim3 grid((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)g.D, 1);
+#define WL_Q1(DD, SCHV) hipLaunchKernelGGL((k_conv_q1<DD, SCHV>), grid, dim3(WL_BLOCK), 0, s, g, Phi, u, nu, per)
+  if (g.D == 3) { if (scheme == WL_QUICK) WL_Q1(3, WL_QUICK); else if (scheme == WL_VANLEER) WL_Q1(3, WL_VANLEER); else WL_Q1(3, WL_CDS); }
+  else { if (scheme == WL_QUICK) WL_Q1(2, WL_QUICK); else if (scheme == WL_VANLEER) WL_Q1(2, WL_VANLEER); else WL_Q1(2, WL_CDS); }
+#undef WL_Q1
+  WL_LAUNCH_CHECK(); return 0;
+}
 // conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: f and u_out written, u_out must not alias u_adv
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
                    float dt, float pre, float post, hipStream_t s) {

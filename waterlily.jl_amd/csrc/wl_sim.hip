@@ -193,6 +193,14 @@ struct wl_sim {
 
   // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
   int bc_u(hipStream_t s) { WL_TRY(wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s)); return wl::halo(comm, u, G, d.D, 2, s); }
+  bool use_convz = false;    // z-marching conv_diff! (each flux once): bit-identical but measured 6 % SLOWER than the gather kernel at 512³ (opt-in)
+  int conv_only(const float* uadv, hipStream_t s) {     // conv_diff!(f,uadv,σ) without BDIM!
+    if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
+      WL_TRY(wl::conv_diff_z(f, uadv, nullptr, nullptr, nullptr, G, d.nu, d.scheme, 0.f, 0.f, 1.f, s));
+      return wl::conv_q1(sigma, uadv, G, d.nu, d.perdir_mask, d.scheme, s);
+    }
+    return wl::conv_diff(f, uadv, sigma, G, d.nu, d.perdir_mask, d.scheme, s);
+  }
   int bdim_step(float pre, float post, hipStream_t s) {
     ProfScope pb(WL_PROF_BDIM, s);
     if (d.has_body && comm) {   // μddn reads f[I±δz] across the slab face: exchange f between the two passes
@@ -206,9 +214,12 @@ struct wl_sim {
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
     if (us && !d.has_body) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
       ProfScope pc(WL_PROF_CONVDIFF, s);
-      WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, s));
+      if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
+        WL_TRY(wl::conv_diff_z(f, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
+        WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
+      } else WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, s));
     } else {
-      { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u0, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
+      { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
       WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
     }
     WL_TRY(bc_u(s));
@@ -218,11 +229,14 @@ struct wl_sim {
   int correct(hipStream_t s) {                                                           // mom_correct! :205-210
     if (us && !d.has_body) {   // the advecting field is u itself: write the new u to the spare array and swap
       { ProfScope pc(WL_PROF_CONVDIFF, s);
-        WL_TRY(wl::conv_diff_bdim(f, u, sigma, u0, mu0, us, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 1.f, 0.5f, s)); }
+        if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
+          WL_TRY(wl::conv_diff_z(f, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
+          WL_TRY(wl::conv_q1(sigma, u, G, d.nu, d.perdir_mask, d.scheme, s));
+        } else WL_TRY(wl::conv_diff_bdim(f, u, sigma, u0, mu0, us, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 1.f, 0.5f, s)); }
       std::swap(u, us);
       return bc_u(s);
     }
-    { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(wl::conv_diff(f, u, sigma, G, d.nu, d.perdir_mask, d.scheme, s)); }
+    { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u, s)); }
     WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
@@ -357,6 +371,12 @@ int wl_sim_init_flow(wl_sim* s, void* st) {                                     
   }
   WL_HIP(hipMemcpyAsync(s->u0, s->u, sizeof(float) * (size_t)s->G.cs * s->d.D, hipMemcpyDeviceToDevice, q));
   return 0;
+}
+int wl_sim_set_option(wl_sim* s, const char* name, int value) {
+  const std::string n(name);
+  if (n == "convz") { s->use_convz = value != 0; return 0; }
+  if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
+  wl_set_error("unknown option " + n); return WL_EINVAL;
 }
 int wl_sim_update(wl_sim* s, void* st) { return s->mg->update(wl_stream(st)); }
 int wl_sim_mom_step(wl_sim* s, void* st) { return s->mom_step(wl_stream(st)); }

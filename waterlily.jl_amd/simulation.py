@@ -122,6 +122,10 @@ class FusedSimulation:
     def update_(self):
         check(lib().wl_sim_update(self._h, stream()))
 
+    def set_option(self, name, value):
+        """implementation switches: "convz", "fused_smoother" (1 = default fast path, 0 = one kernel per pass)"""
+        check(lib().wl_sim_set_option(self._h, name.encode(), int(value)))
+
     @property
     def dt(self):
         out = (C.c_float * 1000000)()
