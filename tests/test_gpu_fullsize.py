@@ -1,0 +1,84 @@
+"""Full-size checks (256³, BASELINE configs[2]) through size-independent properties — the oracle is far too slow here:
+ * the optimised paths (temporally blocked smoother, fused conv_diff!+BDIM!, z-marching conv_diff!) equal the plain
+   one-kernel-per-pass paths BIT FOR BIT after whole time steps;
+ * the projected velocity is divergence free to the solver tolerance, the flow stays finite, kinetic energy decays;
+ * A is symmetric: <Ax,y> == <x,Ay>; restriction is the transpose of prolongation: <restrict r, x_c> == <r, prolong x_c>."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 256
+
+
+@pytest.fixture(scope="module")
+def w():
+    import waterlily_jl_amd as w
+    w.core.device()
+    return w
+
+
+def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
+    sims = {}
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0}), ("zmarch", {"convz": 1})):
+        s = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+        for k, v in opts.items():
+            s.set_option(k, v)
+        for _ in range(2):
+            s.mom_step_()
+        sims[tag] = (s.field("u"), s.field("p"), s.pois_n, s.dt)
+        del s
+    for tag in ("plain", "zmarch"):
+        assert sims[tag][2] == sims["fast"][2] and sims[tag][3] == sims["fast"][3]
+        assert np.array_equal(sims[tag][0], sims["fast"][0]), tag
+        assert np.array_equal(sims[tag][1], sims["fast"][1]), tag
+
+
+def test_projection_is_divergence_free_and_energy_decays(w):
+    s = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+    ke = []
+    for _ in range(4):
+        s.mom_step_()
+        u = s.field("u")
+        assert np.isfinite(u).all()
+        ke.append(float(np.sum(u[1:-1, 1:-1, 1:-1].astype(np.float64) ** 2)))
+        div = (u[2:, 1:-1, 1:-1, 0] - u[1:-1, 1:-1, 1:-1, 0]) + (u[1:-1, 2:, 1:-1, 1] - u[1:-1, 1:-1, 1:-1, 1]) + (u[1:-1, 1:-1, 2:, 2] - u[1:-1, 1:-1, 1:-1, 2])
+        # solver!: L∞(r) < tol=2e-3 on r = dt·(div u*) − A(dt p) ; after the update div(u) = r/ (w·dt) with w·dt ≈ O(0.2..0.5)
+        assert np.abs(div).max() < 2e-3 / (0.5 * float(s.dt[-2])) * 1.01
+        assert np.abs(div).mean() < 2e-4 / (0.5 * float(s.dt[-2])) * 1.01
+    assert all(b < a for a, b in zip(ke, ke[1:])), ke          # wall-bounded viscous TGV only loses energy
+    assert all(1 <= n <= 4 for n in s.pois_n)
+
+
+def test_operator_symmetry_and_transfer_adjointness(w):
+    rng = np.random.default_rng(5)
+    shape = (N + 2,) * 3
+    L = w.jl_zeros(shape + (3,), 1.0)
+    import torch
+    L.copy_(w.to_device(np.asfortranarray(rng.uniform(0.2, 1.0, size=shape + (3,)).astype(np.float32))))
+    w.BC_(L, (0, 0, 0))
+    x, y, z = w.jl_zeros(shape), w.jl_zeros(shape), w.jl_zeros(shape)
+    inner = (slice(1, -1),) * 3
+    x[inner] = torch.rand((N, N, N), device=x.device).permute(2, 1, 0)
+    y[inner] = torch.rand((N, N, N), device=x.device).permute(2, 1, 0)
+    p = w.Poisson(x, L, z)
+    lib = w.lib()
+
+    def dot(a, b):
+        out = C.c_double()
+        w._lib.check(lib.wl_dot(w.core.ptr(a), w.core.ptr(b), a.numel(), C.byref(out), w.core.stream()))
+        return out.value
+    Ax = w.jl_zeros(shape); Ay = w.jl_zeros(shape)
+    w.mult_(p, x); Ax.copy_(p.z)
+    w.mult_(p, y); Ay.copy_(p.z)
+    a, b = dot(Ax, y), dot(x, Ay)
+    assert abs(a - b) <= 2e-6 * max(abs(a), abs(b))
+    # restriction (plain sum over children) is the transpose of prolongation (injection)
+    cshape = (N // 2 + 2,) * 3
+    xc, rc, pf = w.jl_zeros(cshape), w.jl_zeros(cshape), w.jl_zeros(shape)
+    xc[inner] = torch.rand((N // 2,) * 3, device=x.device)
+    w.restrict_(rc, x)
+    w.prolongate_(pf, xc)
+    a, b = dot(rc, xc), dot(x, pf)
+    assert abs(a - b) <= 2e-6 * max(abs(a), abs(b))

@@ -64,7 +64,9 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
       const int nloc = f.k1 - f.k0;
       const int nc = cz ? nloc / 2 : nloc;
       // stay distributed while the local planes pair up and the level is still big; otherwise replicate on every rank
-      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > 32;
+      // levels of <= 64 planes are replicated: their halo exchanges would be pure latency (7 per V-cycle and level) while the
+      // whole level costs less than that to recompute on every rank
+      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > 64;
       if (cz && (nloc % 2 != 0)) { wl_set_error("z-slab: local plane count must stay even until the level is replicated (use nz = P*2^k)"); return WL_EINVAL; }
       if (keep) {
         cgr.gnz = gnz_c; cgr.k0 = f.k0; cgr.k1 = cgr.k0 + nc; cgr.nz = nc + 2 * cgr.k0;
