@@ -126,6 +126,8 @@ def main():
     ncell = float(N) ** 3
     pn = sim.pois_n[n_warm:]
     # dominant kernel: kernel B of the temporally blocked smoother (sweeps 3,4 + increment!) on the finest level
+    if not prof["gsrb_B"]["launches"]:   # experiments with the fused smoother switched off: report the plain colour sweep instead
+        prof["gsrb_B"], prof["gsrb_A"] = prof["gs_sweep"], prof["gs_sweep"]
     kb_ms, ka_ms = prof["gsrb_B"]["avg_ms"], prof["gsrb_A"]["avg_ms"]
     ach = BYTES_GS_B * ncell / (kb_ms * 1e-3) / 1e9
     smooth_ms = prof["smooth"]["avg_ms"]

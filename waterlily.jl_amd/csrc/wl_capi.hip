@@ -122,14 +122,39 @@ int wl_mg::update(hipStream_t s) {                                              
   }
   return 0;
 }
+// the deferred `prolongate!; increment!` of level l, executed on its own (when the next smooth! cannot absorb it)
+int wl_mg::flush_pending(int l, float w, hipStream_t s) {
+  Level& fine = lv[(size_t)l]; Level& coarse = lv[(size_t)l + 1];
+  fine.pend = false;
+  ProfScope pp(l == 0 ? WL_PROF_PROLONG : -1, s);
+  if (perdir) {
+    WL_TRY(wl::prolongate(fine.eps, fine.x_, coarse.x, coarse.x_, s));
+    WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
+    WL_TRY(halo(fine, fine.eps, 1, s));
+    return wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, w, s);
+  }
+  return wl::prolong_increment(fine.r, fine.x, fine.eps, coarse.x, fine.L, fine.D, fine.x_, coarse.x_, w, true, s);
+}
 // GaussSeidelRB!(p;it,ω)                                                                 src/Poisson.jl:141-148
-int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
+int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* norms_done) {
   Level& p = lv[(size_t)l];
+  if (norms_done) *norms_done = false;
+  const bool fused = it == 4 && use_fused && wl::gsrb_fused_ok(p.x_, perdir, p.dist);
+  if (p.pend && !fused) WL_TRY(flush_pending(l, w, s));
   ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
-  if (it == 4 && use_fused && wl::gsrb_fused_ok(p.x_, perdir, p.dist)) {   // two z-marching kernels instead of six passes
-    { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.iD, p.x_, s)); }
-    { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(p.eps, p.rs, p.x, p.em, p.r, p.L, p.D, p.iD, p.x_, w, s)); }
-    std::swap(p.r, p.rs);
+  if (fused) {   // two z-marching kernels instead of six passes (+ the pending prolongation as an extra stage of kernel A)
+    const RedWs* nws = want_norms ? &ws : nullptr;
+    if (p.pend) {
+      Level& coarse = lv[(size_t)l + 1];
+      p.pend = false;
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.D, p.iD, p.x_, coarse.x_, w, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(p.eps, p.r, p.x, p.em, p.rs, p.L, p.D, p.iD, p.x_, w, nws, 2, 1, s)); }
+    } else {
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.iD, p.x_, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(p.eps, p.rs, p.x, p.em, p.r, p.L, p.D, p.iD, p.x_, w, nws, 2, 1, s)); }
+      std::swap(p.r, p.rs);
+    }
+    if (norms_done) *norms_done = want_norms;
     return 0;
   }
   const bool fuse = !perdir && !p.dist && it >= 1;   // ghost ϵ are plain memory reads only on these levels
@@ -147,7 +172,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s) {
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));                                      // perBC!(ϵ) inside increment! :101
   return wl::increment(p.r, p.x, p.eps, p.L, p.D, p.x_, w, s);
 }
-int wl_mg::vcycle(int l, float w, hipStream_t s) {                                        // Vcycle! :88-101
+int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                            // Vcycle! :88-101
   Level& fine = lv[(size_t)l]; Level& coarse = lv[(size_t)l + 1];
   // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
   {
@@ -169,18 +194,15 @@ int wl_mg::vcycle(int l, float w, hipStream_t s) {                              
       WL_TRY(wl::allgather_planes(comm, coarse.r, coarse.view, 1, s));
     } else WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
     WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
-    if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s));
+    if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s, true));                         // its last step may be deferred into the smooth! below
     WL_TRY(smooth(l + 1, 4, w, s));
     WL_TRY(halo(coarse, coarse.x, 1, s));                                                  // prolongation reads the coarse cells under my halo planes
   }
-  ProfScope pp(l == 0 ? WL_PROF_PROLONG : -1, s);
-  if (perdir) {
-    WL_TRY(wl::prolongate(fine.eps, fine.x_, coarse.x, coarse.x_, s));
-    WL_TRY(wl::bc_per_scalar(fine.eps, fine.x_, perdir, s));
-    WL_TRY(halo(fine, fine.eps, 1, s));
-    return wl::increment(fine.r, fine.x, fine.eps, fine.L, fine.D, fine.x_, w, s);
-  }
-  return wl::prolong_increment(fine.r, fine.x, fine.eps, coarse.x, fine.L, fine.D, fine.x_, coarse.x_, w, true, s);
+  // prolongate!(fine.ϵ,coarse.x); increment!(fine;ω): the caller's next operation is smooth!(fine;ω) with the same ω — when that
+  // smooth! runs as the temporally blocked kernel pair it absorbs this step as an extra pipeline stage (defer).
+  if (defer && use_fused && wl::gsrb_fused_ok(fine.x_, perdir, fine.dist)) { fine.pend = true; return 0; }
+  fine.pend = true;
+  return flush_pending(l, w, s);
 }
 int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s) {   // solver! :108-128
   Level& p = lv[0];
@@ -201,9 +223,10 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
   int np = 0;
   log_r1.clear(); log_rinf.clear(); log_w.clear();
   while (np < itmx) {
-    WL_TRY(vcycle(0, w, s));
-    WL_TRY(smooth(0, 4, w, s));
-    WL_TRY(wl::norms_dev(p.r, p.x_, ws, 2, 1, s));                                        // rnew -> res_d[2], r∞ -> res_f[1]
+    WL_TRY(vcycle(0, w, s, true));
+    bool nd = false;
+    WL_TRY(smooth(0, 4, w, s, true, &nd));                                                // fused path: norms come out of kernel B
+    if (!nd) WL_TRY(wl::norms_dev(lv[0].r, p.x_, ws, 2, 1, s));                           // rnew -> res_d[2], r∞ -> res_f[1]
     WL_TRY(wl::combine_results(comm, ws, s));                                             // (slot 0 becomes P·Σr: not used again)
     WL_TRY(wl::read_results(ws, hd, 3, hf, 2, s));
     if (!have_r1) { r1 = (float)hd[1]; log_r1.push_back(hd[1]); log_rinf.push_back(hf[0]); log_w.push_back(1.0); have_r1 = true; }
@@ -355,7 +378,7 @@ float* wl_mg_level_field(const wl_mg* mg, int l, const char* name) {
 }
 int wl_mg_smooth(wl_mg* mg, int l, int it, float w, void* st) { WL_CHECK(l >= 0 && l < (int)mg->lv.size(), "level out of range"); return mg->smooth(l, it <= 0 ? 4 : it, w, wl_stream(st)); }
 int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = on != 0; return 0; }
-int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st)); }
+int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }
 int wl_mg_last_log(const wl_mg* mg, double* r1, double* rinf, double* w, int cap) {

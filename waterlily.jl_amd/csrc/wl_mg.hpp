@@ -9,6 +9,7 @@ struct wl_mg {
     wl_grid g; GridX x_;
     float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
     float *em = nullptr, *rs = nullptr;   // scratch of the fused smoother: ϵ after sweep 2, new residual (ghosts stay zero)
+    bool pend = false;       // the V-cycle's prolongate!+increment! of this level is deferred into the next smooth! (fused kernel A)
     bool dist = false;       // z-slab distributed level (halo exchanges) vs replicated on every rank
     GridX view;              // replicated level fed by a distributed parent: the planes of the full array this rank computes
     bool has_view = false;
@@ -27,7 +28,8 @@ struct wl_mg {
   int halo(Level& v, float* a, int ncomp, hipStream_t s) { return v.dist ? wl::halo(comm, a, v.x_, ncomp, 1, s) : 0; }
   ~wl_mg();
   int update(hipStream_t s);
-  int smooth(int l, int it, float w, hipStream_t s);
-  int vcycle(int l, float w, hipStream_t s);
+  int smooth(int l, int it, float w, hipStream_t s, bool want_norms = false, bool* norms_done = nullptr);
+  int vcycle(int l, float w, hipStream_t s, bool defer = false);
+  int flush_pending(int l, float w, hipStream_t s);
   int solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s);
 };

@@ -347,6 +347,10 @@ int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int s
   hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)grid.x, ws.res_d + slot_d, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
+int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStream_t s) {
+  hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, nparts, ws.res_d + slot_d, ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
 int increment(float* r, float* x, const float* eps, const float* L, const float* Dg, const GridX& g, float w, hipStream_t s) {
   DSEL(g.D, k_increment, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, r, x, eps, L, Dg, w);
   WL_LAUNCH_CHECK(); return 0;
