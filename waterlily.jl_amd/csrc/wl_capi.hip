@@ -204,15 +204,17 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
   fine.pend = true;
   return flush_pending(l, w, s);
 }
-int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s) {   // solver! :108-128
+int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s, bool have_residual) {   // solver! :108-128
   Level& p = lv[0];
   const double r1tol = (tol / 10.0) * (double)wl_ninside_global(p.g);                     // l1n_tol  src/Poisson.jl:194
   const double rinftol = tol;
   {
     ProfScope pr(WL_PROF_RESIDUAL, s);
-    WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                      // residual!: perBC!(x) :93
-    WL_TRY(halo(p, p.x, 1, s));
-    WL_TRY(wl::residual_part(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));               // r and the local Σr -> res_d[0]
+    if (!have_residual) {
+      WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                    // residual!: perBC!(x) :93
+      WL_TRY(halo(p, p.x, 1, s));
+      WL_TRY(wl::residual_part(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));             // r and the local Σr -> res_d[0]
+    }
     WL_TRY(wl::combine_results(comm, ws, s));
     WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));                                  // mean shift + r₁ -> res_d[1], r∞ -> res_f[0]
   }

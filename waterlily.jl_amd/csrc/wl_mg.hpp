@@ -31,5 +31,6 @@ struct wl_mg {
   int smooth(int l, int it, float w, hipStream_t s, bool want_norms = false, bool* norms_done = nullptr);
   int vcycle(int l, float w, hipStream_t s, bool defer = false);
   int flush_pending(int l, float w, hipStream_t s);
-  int solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s);
+  // have_residual: r and the local Σr (ws.res_d[0]) were already produced by the caller's fused div+residual kernel
+  int solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s, bool have_residual = false);
 };

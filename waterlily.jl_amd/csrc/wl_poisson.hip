@@ -69,6 +69,59 @@ __global__ void k_residual(GridX g, float* __restrict__ r, const float* __restri
   acc = block_sum(acc);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
+// mom_project! head (src/Flow.jl:225) + residual! (src/Poisson.jl:92-95) in ONE pass:
+//   z = div(u) ; x_out = x·dt (ALL cells) ; r = iD==0 ? 0 : z − A·(x·dt), with block partial sums of r.
+// x_out ≠ x (neighbours still read the unscaled x; x·dt of a neighbour is recomputed — the same product bit for bit).
+template <int D>
+__global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict__ xout, float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ u,
+                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  double acc = 0.0;
+  const int nsl = wl_nslots(g);
+  if (cell_ij(g, m, i, j)) {
+    const bool inij = interior_ij(g, i, j);
+    for (int k = pz; k < g.nz; k += nsl) {
+      const long o = m + (long)k * g.sz;
+      const float xs = x[o] * dt;
+      xout[o] = xs;
+      bool in = inij;
+      if (D == 3) in = in && k >= g.k0 && k < g.k1;
+      if (!in) continue;
+      float dv = 0.f;
+      dv += u[o + 1] - u[o];
+      dv += u[g.cs + o + g.sy] - u[g.cs + o];
+      if (D == 3) dv += u[2 * g.cs + o + g.sz] - u[2 * g.cs + o];
+      z[o] = dv;
+      float s = xs * Dg[o];
+      s += ((x[o - 1] * dt) * L[o] + (x[o + 1] * dt) * L[o + 1]);
+      s += ((x[o - g.sy] * dt) * L[g.cs + o] + (x[o + g.sy] * dt) * L[g.cs + o + g.sy]);
+      if (D == 3) s += ((x[o - g.sz] * dt) * L[2 * g.cs + o] + (x[o + g.sz] * dt) * L[2 * g.cs + o + g.sz]);
+      const float v = (iD[o] == 0.f) ? 0.f : dv - s;
+      r[o] = v;
+      acc += (double)v;
+    }
+  }
+  acc = block_sum(acc);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+// mom_project! tail (src/Flow.jl:227-230): u[I,i] -= L[I,i]·∂ᵢx ; p_out = x/dt (ALL cells), p_out ≠ x
+template <int D>
+__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = pz;
+  const long o = m + (long)k * g.sz;
+  const float xc = x[o];
+  pout[o] = xc / dt;
+  bool in = interior_ij(g, i, j);
+  if (D == 3) in = in && k >= g.k0 && k < g.k1;
+  if (!in) return;
+  u[o] -= L[o] * (xc - x[o - 1]);
+  u[g.cs + o] -= L[g.cs + o] * (xc - x[o - g.sy]);
+  if (D == 3) u[2 * g.cs + o] -= L[2 * g.cs + o] * (xc - x[o - g.sz]);
+}
 // deterministic second stage: res_d[slot] = Σ partials
 __global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
   double a = 0.0;
@@ -331,6 +384,16 @@ int residual_part(float* r, const float* x, const float* z, const float* L, cons
   dim3 grid = wl_plane_grid(g, wl_red_slots(g, np));
   DSEL(g.D, k_residual, grid, dim3(WL_BLOCK), 0, s, g, r, x, z, L, Dg, iD, ws.pa);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* Dg, const float* iD, const GridX& g, float dt, const RedWs& ws, hipStream_t s) {
+  dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.nz));
+  DSEL(g.D, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, hipStream_t s) {
+  DSEL(g.D, k_project_unscale, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt);
   WL_LAUNCH_CHECK(); return 0;
 }
 int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s) {

@@ -187,6 +187,8 @@ struct wl_sim {
   wl_mg* mg = nullptr;
   wl_comm* comm = nullptr;   // not owned; NULL for a single domain
   bool swap_ok = false;      // u and u⁰ are handle-owned and every ghost of u is rewritten by BC! (no exitBC)
+  float* ps = nullptr;       // spare pressure array (out-of-place x·dt and x/dt around the solve; two swaps restore p's identity)
+  bool use_fuse_p = true;
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
   ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
@@ -242,6 +244,17 @@ struct wl_sim {
   }
   int project(float w, hipStream_t s) {                                                  // mom_project! :223-232
     const float dtl = w * dt.back();
+    if (ps && use_fuse_p && !d.perdir_mask && !comm) {
+      // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
+      wl_mg::Level& l0 = mg->lv[0];
+      { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(sigma, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, s)); }
+      std::swap(p, ps); l0.x = p;
+      WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
+      // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
+      WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, s));
+      std::swap(p, ps); l0.x = p;
+      return bc_u(s);
+    }
     WL_TRY(wl::div_scale(sigma, p, u, G, dtl, s));                                       // z=div(u); x.*=dt
     WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s));
     WL_TRY(wl::project(u, mu0, p, G, s));
@@ -325,6 +338,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   size_t total = 0;
   const bool want_us = !desc->u && !desc->u0 && !desc->exitBC && !desc->has_body;
   if (want_us) total += nc * D;
+  total += nc;   // ps
   for (int q = 0; q < 8; q++) if (!given[q] && !(q == 7 && !desc->has_body) && !(q == 5 && !desc->has_body)) total += sz[q];
   if (total) { hipError_t e = hipMalloc((void**)&s->own, total * sizeof(float)); if (e != hipSuccess) { delete s; wl_set_error("hipMalloc failed for flow arrays"); return (int)e; } (void)hipMemset(s->own, 0, total * sizeof(float)); }
   float* pcur = s->own;
@@ -334,6 +348,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     else { *ptrs[q] = pcur; pcur += sz[q]; }
   }
   if (want_us) { s->us = pcur; pcur += nc * D; }
+  s->ps = pcur; pcur += nc;
   s->dt.assign(1, desc->dt0);
   s->swap_ok = !desc->u && !desc->u0 && !desc->exitBC;
   // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
@@ -376,6 +391,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   const std::string n(name);
   if (n == "convz") { s->use_convz = value != 0; return 0; }
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
+  if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
 int wl_sim_update(wl_sim* s, void* st) { return s->mg->update(wl_stream(st)); }

@@ -33,9 +33,9 @@ class CallbackComm:
     library's buffers and host memory: wl_d2h / wl_h2d on a GPU, plain memmove when the 'device' buffers are host
     arrays (CPU tests of the halo plumbing)."""
 
-    def __init__(self, dist, rank=None, size=None, host_buffers=False):
+    def __init__(self, dist, rank=None, size=None, host_buffers=False, group=None):
         import torch
-        self.torch, self.dist = torch, dist
+        self.torch, self.dist, self.group = torch, dist, group
         self.rank = dist.get_rank() if rank is None else rank
         self.size = dist.get_world_size() if size is None else size
         L = lib()
@@ -60,15 +60,15 @@ class CallbackComm:
             reqs, keep = [], []
             if slo:
                 b = np.empty(nbytes, dtype=np.uint8); self._out(b, slo, nbytes); t = torch.from_numpy(b); keep.append(t)
-                reqs.append(dist.isend(t, self.rank - 1))
+                reqs.append(dist.isend(t, self.rank - 1, group=self.group))
             if shi:
                 b = np.empty(nbytes, dtype=np.uint8); self._out(b, shi, nbytes); t = torch.from_numpy(b); keep.append(t)
-                reqs.append(dist.isend(t, self.rank + 1))
+                reqs.append(dist.isend(t, self.rank + 1, group=self.group))
             rl = rh = None
             if rlo:
-                rl = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rl, self.rank - 1))
+                rl = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rl, self.rank - 1, group=self.group))
             if rhi:
-                rh = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rh, self.rank + 1))
+                rh = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rh, self.rank + 1, group=self.group))
             for r in reqs:
                 r.wait()
             if rl is not None:
@@ -86,7 +86,7 @@ class CallbackComm:
             self._sync(stream)
             b = np.empty(nbytes, dtype=np.uint8); self._out(b, send, nbytes)
             outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.size)]
-            dist.all_gather(outs, torch.from_numpy(b))
+            dist.all_gather(outs, torch.from_numpy(b), group=self.group)
             for r, t in enumerate(outs):
                 self._in(recv + r * nbytes, t.numpy(), nbytes)
             return 0
@@ -203,8 +203,23 @@ class SlabSimulation:
 
 
 def make_comm(dist, device, prefer="rccl"):
+    """RCCL transport when the process group is nccl(=RCCL); if creating it fails on ANY rank, every rank falls back
+    (decided by an all-reduce, so nobody is left waiting) to the host-staged callback transport over a gloo group."""
+    import torch
     if prefer == "rccl" and dist.get_backend() == "nccl":
-        return RcclComm(dist, device)
+        comm, ok = None, 1
+        try:
+            comm = RcclComm(dist, device)
+        except Exception as e:   # noqa: BLE001
+            print(f"[rank {dist.get_rank()}] RCCL transport unavailable ({e!r}); falling back to host staging", flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.destroy()
+        return CallbackComm(dist, group=dist.new_group(backend="gloo"))
     return CallbackComm(dist)
 
 
