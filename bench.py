@@ -24,6 +24,8 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 # algorithmic bytes per interior cell (SURVEY §8d / BASELINE.md §4), f32, 3-D
 BYTES_SMOOTH_OP = 40.0    # GaussSeidelRB!(it=4) as ONE operation: R r,iD,L₁₋₃,D,x  W ϵ,r,x
 BYTES_GS_A = 24.0         # kernel A of the temporally blocked smoother: R r,iD,L₁₋₃  W ϵ_mid
+BYTES_GS_A_PRO = 40.5     # kernel A with the V-cycle's prolongate!+increment! folded in: R r,x,L₁₋₃,D,iD,x_c/8  W r',x,ϵ_mid
+BYTES_PROLONG_INC = 36.5  # prolongate!+increment! as reference operations (src/MultiLevelPoisson.jl:99-100)
 BYTES_GS_B = 44.0         # kernel B: R ϵ_mid,r,iD,L₁₋₃,D,x  W ϵ,r',x
 
 
@@ -131,6 +133,9 @@ def main():
     kb_ms, ka_ms = prof["gsrb_B"]["avg_ms"], prof["gsrb_A"]["avg_ms"]
     ach = BYTES_GS_B * ncell / (kb_ms * 1e-3) / 1e9
     smooth_ms = prof["smooth"]["avg_ms"]
+    pro_fused = prof["prolong_increment"]["launches"] == 0       # the smooth slot then also contains prolongate!+increment!
+    bytes_a = BYTES_GS_A_PRO if pro_fused else BYTES_GS_A
+    bytes_op = BYTES_SMOOTH_OP + (BYTES_PROLONG_INC if pro_fused else 0.0)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     tsrc = None
@@ -150,10 +155,13 @@ def main():
         "roofline": {"bound": "hbm", "kernel": "k_gsrb_B (finest-level GaussSeidelRB!: colour sweeps 3,4 + increment!, src/Poisson.jl:141-148)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                      "bytes_per_cell": BYTES_GS_B, "avg_launch_ms": kb_ms, "launches": prof["gsrb_B"]["launches"],
-                     "kernel_A": {"what": "k_gsrb_A: eps=r*iD + colour sweeps 1,2, 24 B/cell", "avg_ms": ka_ms,
-                                  "achieved": BYTES_GS_A * ncell / (ka_ms * 1e-3) / 1e9, "frac": BYTES_GS_A * ncell / (ka_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                     "smooth_op": {"what": "GaussSeidelRB!(it=4) as ONE operation (kernels A+B), 40 B/cell", "avg_ms": smooth_ms,
-                                   "achieved": BYTES_SMOOTH_OP * ncell / (smooth_ms * 1e-3) / 1e9, "frac": BYTES_SMOOTH_OP * ncell / (smooth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                     "kernel_A": {"what": ("k_gsrb_A<PRO>: prolongate!+increment! + eps=r*iD + colour sweeps 1,2" if pro_fused else "k_gsrb_A: eps=r*iD + colour sweeps 1,2"),
+                                  "bytes_per_cell": bytes_a, "avg_ms": ka_ms,
+                                  "achieved": bytes_a * ncell / (ka_ms * 1e-3) / 1e9, "frac": bytes_a * ncell / (ka_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                     "smooth_op": {"what": ("prolongate!+increment! (36.5 B/cell) + GaussSeidelRB!(it=4) (40 B/cell) as the reference's operations, executed as kernels A<PRO>+B"
+                                            if pro_fused else "GaussSeidelRB!(it=4) as ONE operation (kernels A+B), 40 B/cell"),
+                                   "bytes_per_cell": bytes_op, "avg_ms": smooth_ms,
+                                   "achieved": bytes_op * ncell / (smooth_ms * 1e-3) / 1e9, "frac": bytes_op * ncell / (smooth_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}},
         "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items()},
     }
     if not args.no_cpu_baseline:

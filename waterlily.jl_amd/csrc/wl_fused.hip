@@ -13,8 +13,12 @@
 // (true for the arrays a wl_mg handle owns), so `r·iD` of a ghost cell reproduces the stored ghost ϵ (=0).
 #include "wl_common.hpp"
 
+#ifndef ZT_X
 #define ZT_X 64
+#endif
+#ifndef ZT_Y
 #define ZT_Y 16
+#endif
 #define ZT_N (ZT_X * ZT_Y)
 #define ZT_LDS ((ZT_Y + 2) * ZT_X)   // one guard row above and below: neighbour indices never leave the array
 
@@ -43,7 +47,7 @@ __device__ __forceinline__ ZTile ztile(const GridX& g, int zchunk) {
   const int tl = (int)(q * per + (s - (unsigned)c * per));
   t.alive = tl < ntiles;
   const int tx = tl % ntx, ty = tl / ntx;
-  const int lx = threadIdx.x & (ZT_X - 1), ly = threadIdx.x >> 6;
+  const int lx = threadIdx.x % ZT_X, ly = threadIdx.x / ZT_X;
   t.i = 1 + tx * CX - H + lx;
   t.j = 1 + ty * CY - H + ly;
   t.li = ZT_X + lx + ly * ZT_X;
