@@ -1,6 +1,8 @@
 // Flow-side kernels for gfx950: conv_diff! (gather form), BDIM!, BC!, div, projection, CFL and the
 // generic array ops.  Reference semantics: /root/reference/src/Flow.jl, src/core.jl (file:line per kernel).
 // Arithmetic order follows the reference statement by statement (-ffp-contract=off).
+#include <cstdlib>
+
 #include "wl_common.hpp"
 
 namespace {
@@ -66,8 +68,16 @@ __global__ void k_fin_max(const float* __restrict__ pmax, int n, float* __restri
 // median(a,b,c) src/Flow.jl:27-36 — one v_med3_f32; identical value to the reference's branchy form for non-NaN inputs
 // (the branchy form compiled to ~700 exec-mask instructions per cell in conv_diff!).
 __device__ __forceinline__ float median3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// x/6 correctly rounded without the ~10-instruction IEEE division sequence: float(double(x)·(1/6)) equals x/6 for EVERY
+// float x (verified exhaustively over all 2^24 significands × normal/subnormal exponents, tools/check_div6.py): the
+// quotient of a float by 6 is never closer than ~2^-27 (relative) to a rounding midpoint, far above the 2^-53 product error.
+#ifdef WL_NO_DIV6
+__device__ __forceinline__ float div6(float x) { return x / 6; }
+#else
+__device__ __forceinline__ float div6(float x) { return (float)((double)x * (1.0 / 6.0)); }
+#endif
 template <int SCH> __device__ __forceinline__ float lam(float u, float c, float d) {
-  if (SCH == WL_QUICK) return median3((5 * c + 2 * d - u) / 6, c, median3(10 * c - 9 * u, c, d));
+  if (SCH == WL_QUICK) return median3(div6(5 * c + 2 * d - u), c, median3(10 * c - 9 * u, c, d));
   if (SCH == WL_VANLEER) return (c <= fminf(u, d) || c >= fmaxf(u, d)) ? c : c + (d - c) * (c - u) / (d - u);
   return (c + d) / 2;
 }
@@ -124,11 +134,30 @@ __device__ __forceinline__ float face_flux(float U, float t0, float t1, float t2
 // FUSE = 1 appends BDIM! for the NoBody case (μ₁≡0, V≡0; src/Flow.jl:176-180 + the folded scale_u!):
 //   f = u⁰ + Δt·r (all cells) ; u_out = (u·pre + μ₀·f)·post (interior).  u_out must not alias the advecting field u.
 struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre, post; int scale_after; };
-template <int D, int SCH, int PER, typename IDX, int FUSE>
+// XSH = 1 (non-periodic only): the flux through a cell's +x face is its x-neighbour's lower-face flux, fetched from lane+1
+// by a wave shuffle instead of being recomputed (3 of the 18 fluxes per cell).  Waves then overlap by one lane: 63 cells
+// per wave, the last lane only feeds lane 62.
+template <int D, int SCH, int PER, typename IDX, int FUSE, int XSH>
 __global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst, BdimArgs bd) {
   int i, j; long m; int pz;
-  wl_tile(g, m, pz);
-  if (!cell_ij(g, m, i, j)) return;
+  bool valid, store;
+  if (XSH) {
+    const unsigned h = blockIdx.x, q8 = h & 7u, sq = h >> 3;
+    const long nbx = (g.sz + 251) / 252;                       // 4 waves × 63 cells per block
+    const unsigned per8 = (unsigned)((nbx + 7) >> 3);
+    pz = (int)(sq / per8);
+    const long bx = (long)q8 * per8 + (sq - (unsigned)pz * per8);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    m = (bx * 4 + wv) * 63 + lane;
+    valid = m < g.sz;
+    store = valid && lane < 63;
+    if (!valid) m = g.sz - 1;                                  // keep every lane alive for the shuffle; nothing is stored
+    j = (int)(m / g.nx); i = (int)(m - (long)j * g.nx);
+  } else {
+    wl_tile(g, m, pz);
+    if (!cell_ij(g, m, i, j)) return;
+    valid = store = true;
+  }
   const int k = (D == 3) ? kfirst + pz : 0;
   const IDX o = (IDX)(m + (long)k * g.sz);
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2};    // Julia (global) indices
@@ -150,6 +179,18 @@ __global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restri
       const bool pb = PER && ((per >> b) & 1u);
       const bool con = ok && (I[b] <= N[b] - 1);
       const bool lowb = (I[b] == 2), upb = (I[b] + 1 == N[b]);
+      if (XSH && b == 0) {   // x faces: own lower-face flux for every cell whose face exists (upper ghost included), upper from lane+1
+        const bool topb = (I[0] == N[0]);
+        const IDX s1 = ok ? 1 : 0;
+        const float fm1 = f[o - s1], fm2 = f[o - (lowb ? s1 : 2 * s1)], fp1 = f[o + ((ok && !topb) ? 1 : 0)];
+        const float Ul = (ub[o] + ub[o - sa]) / 2;
+        const bool posl = Ul > 0;
+        const float Pl = face_flux<SCH>(Ul, posl ? fm2 : fp1, posl ? fm1 : f0, posl ? f0 : fm1, (f0 + fm1) / 2, (lowb && posl) || (topb && (Ul < 0)), f0, fm1, nu);
+        const float Pu = __shfl_down(Pl, 1, 64);
+        acc = con ? acc + Pl : acc;
+        acc = con ? acc - Pu : acc;
+        continue;
+      }
       const IDX sb = con ? st[b] : 0;
       // star of f along b, clamped where the variant never reads it
       const IDX om2 = lowb ? (pb ? (IDX)(N[b] - 4) * sb : -sb) : -2 * sb;       // far upwind of my lower face (ϕuP wraps)
@@ -179,6 +220,7 @@ __global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restri
     if (D == 3) in = in && k >= g.k0 && k < g.k1;
 #pragma unroll
     for (int a = 0; a < D; a++) {
+      if (!store) break;
       const long oa = (long)a * g.cs + o;
       const float fn = bd.u0[oa] + bd.dt * out[a] - 0.f;
       r[oa] = fn;
@@ -191,6 +233,7 @@ __global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restri
     }
     return;
   }
+  if (!store) return;
 #pragma unroll
   for (int a = 0; a < D; a++) r[(long)a * g.cs + o] = out[a];
 }
@@ -508,11 +551,17 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
-  const dim3 grid = wl_plane_grid(g, klast - kfirst);
+  static int xsh_env = -1;
+  if (xsh_env < 0) { const char* e = getenv("WL_CONV_XSH"); xsh_env = e ? atoi(e) : 0; }   // measured SLOWER at 512³ (7.0 vs 6.3 ms/step): opt-in only
+  const bool xsh = (per == 0) && xsh_env;   // +x face fluxes by wave shuffle: 63 cells per wave
+  const long nbx = xsh ? (g.sz + 251) / 252 : 0;
+  const dim3 grid = xsh ? dim3((unsigned)(8L * ((nbx + 7) >> 3) * (klast - kfirst))) : wl_plane_grid(g, klast - kfirst);
   const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
   BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0};
   const BdimArgs ba = bd ? *bd : b0;
-#define WL_CD(PERF, IDXT, FUSEF) hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba)
+#define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \
+  do { if (xsh) hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF, 1 - PERF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba); \
+       else hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF, 0>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba); } while (0)
   if (bd) { if (per) { if (small) WL_CD(1, int, 1); else WL_CD(1, long, 1); } else { if (small) WL_CD(0, int, 1); else WL_CD(0, long, 1); } }
   else    { if (per) { if (small) WL_CD(1, int, 0); else WL_CD(1, long, 0); } else { if (small) WL_CD(0, int, 0); else WL_CD(0, long, 0); } }
 #undef WL_CD
