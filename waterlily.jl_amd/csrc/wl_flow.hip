@@ -138,7 +138,10 @@ struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre,
 // by a wave shuffle instead of being recomputed (3 of the 18 fluxes per cell).  Waves then overlap by one lane: 63 cells
 // per wave, the last lane only feeds lane 62.
 template <int D, int SCH, int PER, typename IDX, int FUSE, int XSH>
-__global__ void __launch_bounds__(WL_BLOCK) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst, BdimArgs bd) {
+#ifndef WL_CD_WAVES
+#define WL_CD_WAVES 1
+#endif
+__global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst, BdimArgs bd) {
   int i, j; long m; int pz;
   bool valid, store;
   if (XSH) {
