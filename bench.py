@@ -23,10 +23,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec, ≈6.3 achievable)
 # algorithmic bytes per interior cell (SURVEY §8d / BASELINE.md §4), f32, 3-D
 BYTES_SMOOTH_OP = 40.0    # GaussSeidelRB!(it=4) as ONE operation: R r,iD,L₁₋₃,D,x  W ϵ,r,x
-BYTES_GS_A = 24.0         # kernel A of the temporally blocked smoother: R r,iD,L₁₋₃  W ϵ_mid
-BYTES_GS_A_PRO = 40.5     # kernel A with the V-cycle's prolongate!+increment! folded in: R r,x,L₁₋₃,D,iD,x_c/8  W r',x,ϵ_mid
+BYTES_GS_A = 20.0         # kernel A of the temporally blocked smoother: R r,L₁₋₃  W ϵ_mid   (D, iD recomputed from L in registers)
+BYTES_GS_A_PRO = 32.5     # kernel A with the V-cycle's prolongate!+increment! folded in: R r,x,L₁₋₃,x_c/8  W r',x,ϵ_mid
 BYTES_PROLONG_INC = 36.5  # prolongate!+increment! as reference operations (src/MultiLevelPoisson.jl:99-100)
-BYTES_GS_B = 44.0         # kernel B: R ϵ_mid,r,iD,L₁₋₃,D,x  W ϵ,r',x
+BYTES_GS_B = 32.0         # kernel B: R ϵ_mid,r,L₁₋₃,x  W r',x   (D, iD recomputed; the final ϵ is not stored by the composite)
 
 
 def cpu_baseline(n=128, warm=2, steps=None, budget_s=12.0):

@@ -147,11 +147,11 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     if (p.pend) {
       Level& coarse = lv[(size_t)l + 1];
       p.pend = false;
-      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.D, p.iD, p.x_, coarse.x_, w, s)); }
-      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(p.eps, p.r, p.x, p.em, p.rs, p.L, p.D, p.iD, p.x_, w, nws, 2, 1, s)); }
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, s)); }
     } else {
-      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.iD, p.x_, s)); }
-      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(p.eps, p.rs, p.x, p.em, p.r, p.L, p.D, p.iD, p.x_, w, nws, 2, 1, s)); }
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.x_, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, p.x_, w, nws, 2, 1, s)); }
       std::swap(p.r, p.rs);
     }
     if (norms_done) *norms_done = want_norms;
@@ -379,7 +379,7 @@ float* wl_mg_level_field(const wl_mg* mg, int l, const char* name) {
   return nullptr;
 }
 int wl_mg_smooth(wl_mg* mg, int l, int it, float w, void* st) { WL_CHECK(l >= 0 && l < (int)mg->lv.size(), "level out of range"); return mg->smooth(l, it <= 0 ? 4 : it, w, wl_stream(st)); }
-int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = on != 0; return 0; }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

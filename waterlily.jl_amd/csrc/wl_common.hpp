@@ -204,9 +204,9 @@ int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, 
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, hipStream_t s);
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
-int gsrb_fused_A(float* emid, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s);
-int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const float* D, const float* iD, const GridX& g, const GridX& gc, float w, hipStream_t s);
-int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const float* D, const float* iD, const GridX& g, float w,
+int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, hipStream_t s);
+int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, hipStream_t s);
+int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
                  const RedWs* ws, int slot_d, int slot_f, hipStream_t s);
 int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStream_t s);
 int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s);

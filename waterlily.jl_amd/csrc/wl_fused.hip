@@ -1,7 +1,8 @@
 // Temporally blocked red–black Gauss–Seidel for gfx950: GaussSeidelRB!(it=4) (src/Poisson.jl:141-148) in TWO
 // z-marching kernels instead of six passes over HBM.
-//   kernel A:  ϵ = r·iD ; colour sweep 1 ; colour sweep 2                 R r,iD,L (20 B/cell)            W ϵ_mid (4)
-//   kernel B:  colour sweep 3 ; colour sweep 4 ; increment!(ω)            R ϵ_mid,r,iD,L,D,x (32)         W ϵ,r',x (12)
+//   kernel A:  ϵ = r·iD ; colour sweep 1 ; colour sweep 2                 R r,L (16 B/cell)               W ϵ_mid (4)
+//   kernel B:  colour sweep 3 ; colour sweep 4 ; increment!(ω)            R ϵ_mid,r,L,x (24)              W r',x[,ϵ] (8-12)
+// (D and iD are recomputed from the face coefficients L that the stencil needs anyway.)
 // A workgroup owns an x-y tile of 64×16 threads (one cell column per thread) and marches along z.  Each stage lags
 // the previous one by one plane, so a cell's z-neighbours are the thread's own registers; x-y neighbours come from LDS
 // (two or three double-buffered 64×16 planes).  Tiles overlap by the dependency depth (2 resp. 3 cells per side): halo
@@ -76,16 +77,28 @@ __device__ __forceinline__ float gs_val(float r, float iD, float exm, float exp_
   return s * iD;
 }
 
+// D and iD are functions of the six face coefficients around a cell (set_diag!, src/Poisson.jl:43-55).  The kernels load those
+// coefficients anyway, so both are recomputed in registers — same operation order, hence the same bits as the stored arrays —
+// instead of streaming 8 B/cell from HBM.
+__device__ __forceinline__ float diag6(float lx, float lxp, float ly, float lyp, float lz, float lzp) {
+  float s = 0.f;
+  s -= (lx + lxp);
+  s -= (ly + lyp);
+  s -= (lz + lzp);
+  return s;
+}
+__device__ __forceinline__ float inv_diag(float d) { return (d == 0.f) ? d : 1.0f / d; }
+
 // ------------------------------------------------------------------------------------------------------------------
 // kernel A.  PRO = 1 prepends the Vcycle!'s `prolongate!(ϵ,x_c); increment!(ω)` (src/MultiLevelPoisson.jl:99-100) as one
 // more pipeline stage on the newest plane: r' = r − ω·A(x_c[down]) , x += ω·x_c[down]; sweeps then start from r'.
 // Every thread (halo included) derives r' of its own column from global data only, so the tile halo stays 2.
 // ------------------------------------------------------------------------------------------------------------------
-struct ProArgs { const float* xc; const float* Dg; float* x; float* rnew; GridX gc; int cx, cy, cz; float w; };
+struct ProArgs { const float* xc; float* x; float* rnew; GridX gc; int cx, cy, cz; float w; };
 __device__ __forceinline__ int dwn(int i, int c) { return c ? (i + 1) / 2 : i; }   // down(I,c), 0-based   :7
 
 template <int PRO>
-__global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__ emid, const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ iD, int zchunk, ProArgs pa) {
+__global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__ emid, const float* __restrict__ r, const float* __restrict__ L, int zchunk, ProArgs pa) {
   __shared__ float sA[2][ZT_LDS];   // ϵ⁰ of the newest plane           (x-y neighbours of sweep 1 one step later)
   __shared__ float sB[2][ZT_LDS];   // ϵ after sweep 1 of plane K-1     (x-y neighbours of sweep 2 one step later)
   const ZTile t = ztile<2>(g, zchunk);
@@ -95,7 +108,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
   // rolling registers; index 0 = plane K, 1 = K-1, 2 = K-2, 3 = K-3
   float e0 = 0, e1 = 0, e2 = 0, e3 = 0;
   float r0 = 0, r1 = 0, r2 = 0, d0 = 0, d1 = 0, d2 = 0, lz0 = 0, lz1 = 0, lz2 = 0;
-  float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0;
+  float lx0 = 0, lxp0 = 0, ly0 = 0, lyp0 = 0, lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0;
   const int Kbeg = t.ks - 2, Kend = t.ke + 1;     // planes whose ϵ⁰ is needed
   // coarse columns under this cell and its x/y neighbours (PRO)
   long c00 = 0, cxm = 0, cxp = 0, cym = 0, cyp = 0;
@@ -105,39 +118,36 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
     cym = dwn(t.i, pa.cx) + (long)dwn(t.j - 1, pa.cy) * pa.gc.sy; cyp = dwn(t.i, pa.cx) + (long)dwn(t.j + 1, pa.cy) * pa.gc.sy;
   }
   // operands of the NEXT step are fetched one plane ahead so that their latency overlaps this step's barrier and arithmetic
-  float n_r0, n_d0, n_lz0, n_lx, n_lxp, n_ly, n_lyp;            // in-plane L: plane K-1 (PRO=0) / plane K (PRO=1)
+  float n_r0, n_lz0, n_lzp, n_lx, n_lxp, n_ly, n_lyp;
   auto fetch = [&](int K) {
     const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
     const long o0 = t.oc + (long)K * g.sz;
-    n_r0 = pl0 ? r[o0] : 0.f; n_d0 = pl0 ? iD[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
-    const int Kl = PRO ? K : K - 1;
-    const bool pll = t.inter && Kl >= g.k0 && Kl < g.k1;
-    const long ol = t.oc + (long)Kl * g.sz;
-    n_lx = pll ? Lx[ol] : 0.f; n_lxp = pll ? Lx[ol + 1] : 0.f; n_ly = pll ? Ly[ol] : 0.f; n_lyp = pll ? Ly[ol + g.sy] : 0.f;
+    n_r0 = pl0 ? r[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
+    const bool pll = t.inter && K >= g.k0 && K < g.k1;           // interior cell of plane K: its six face coefficients
+    n_lx = pll ? Lx[o0] : 0.f; n_lxp = pll ? Lx[o0 + 1] : 0.f; n_ly = pll ? Ly[o0] : 0.f; n_lyp = pll ? Ly[o0 + g.sy] : 0.f;
+    n_lzp = pll ? Lz[o0 + g.sz] : 0.f;
   };
   fetch(Kbeg);
-  float lx0 = 0, lxp0 = 0, ly0 = 0, lyp0 = 0;
   for (int K = Kbeg; K <= Kend; K++) {
     // ---- shift the pipeline
     e3 = e2; e2 = e1; e1 = e0; r2 = r1; r1 = r0; d2 = d1; d1 = d0; lz2 = lz1; lz1 = lz0;
-    lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1;
-    r0 = n_r0; d0 = n_d0; lz0 = n_lz0;
-    if (PRO) { lx1 = lx0; lxp1 = lxp0; ly1 = ly0; lyp1 = lyp0; lx0 = n_lx; lxp0 = n_lxp; ly0 = n_ly; lyp0 = n_lyp; }
-    else { lx1 = n_lx; lxp1 = n_lxp; ly1 = n_ly; lyp1 = n_lyp; }
+    lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1; lx1 = lx0; lxp1 = lxp0; ly1 = ly0; lyp1 = lyp0;
+    r0 = n_r0; lz0 = n_lz0; lx0 = n_lx; lxp0 = n_lxp; ly0 = n_ly; lyp0 = n_lyp;
+    const float lzp0 = n_lzp;
     const long o0 = t.oc + (long)K * g.sz;
-    if (PRO) {
-      const bool pl = t.inter && K >= g.k0 && K < g.k1;
-      if (pl) {   // increment!(fine;ω) with ϵ = x_c[down(I)]          src/Poisson.jl:100-104, mult :70-76
-        const int Kg = g.gk + K;
-        const long ck0 = (long)(dwn(Kg, pa.cz) - pa.gc.gk) * pa.gc.sz, ckm = (long)(dwn(Kg - 1, pa.cz) - pa.gc.gk) * pa.gc.sz, ckp = (long)(dwn(Kg + 1, pa.cz) - pa.gc.gk) * pa.gc.sz;
-        const float ep = pa.xc[c00 + ck0];
-        float s = ep * pa.Dg[o0];
-        s += (pa.xc[cxm + ck0] * lx0 + pa.xc[cxp + ck0] * lxp0);
-        s += (pa.xc[cym + ck0] * ly0 + pa.xc[cyp + ck0] * lyp0);
-        s += (pa.xc[c00 + ckm] * lz0 + pa.xc[c00 + ckp] * Lz[o0 + g.sz]);
-        r0 = r0 - pa.w * s;
-        if (t.core && K >= t.ks && K < t.ke) { pa.rnew[o0] = r0; pa.x[o0] = pa.x[o0] + pa.w * ep; }
-      }
+    const bool pl = t.inter && K >= g.k0 && K < g.k1;
+    const float dg0 = pl ? diag6(lx0, lxp0, ly0, lyp0, lz0, lzp0) : 0.f;     // D[I]   (ghost cells: stored D is 0)
+    d0 = inv_diag(dg0);                                                      // iD[I]
+    if (PRO && pl) {   // increment!(fine;ω) with ϵ = x_c[down(I)]          src/Poisson.jl:100-104, mult :70-76
+      const int Kg = g.gk + K;
+      const long ck0 = (long)(dwn(Kg, pa.cz) - pa.gc.gk) * pa.gc.sz, ckm = (long)(dwn(Kg - 1, pa.cz) - pa.gc.gk) * pa.gc.sz, ckp = (long)(dwn(Kg + 1, pa.cz) - pa.gc.gk) * pa.gc.sz;
+      const float ep = pa.xc[c00 + ck0];
+      float s = ep * dg0;
+      s += (pa.xc[cxm + ck0] * lx0 + pa.xc[cxp + ck0] * lxp0);
+      s += (pa.xc[cym + ck0] * ly0 + pa.xc[cyp + ck0] * lyp0);
+      s += (pa.xc[c00 + ckm] * lz0 + pa.xc[c00 + ckp] * lzp0);
+      r0 = r0 - pa.w * s;
+      if (t.core && K >= t.ks && K < t.ke) { pa.rnew[o0] = r0; pa.x[o0] = pa.x[o0] + pa.w * ep; }
     }
     if (K < Kend) fetch(K + 1);
     const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
@@ -158,12 +168,13 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// kernel B.  NORMS = 1 also reduces L₁ = Σ|r'| and L∞ = max|r'| of the new residual (src/Poisson.jl:190-191) per workgroup
+// kernel B.  NORMS = 1 also reduces L₁ = Σ|r'| and L∞ = max|r'| of the new residual (src/Poisson.jl:190-191) per workgroup;
+// EPS = 1 stores the final ϵ (p.ϵ of the reference; nothing on the path reads it again).
 // ------------------------------------------------------------------------------------------------------------------
-template <int NORMS>
+template <int NORMS, int EPS>
 __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__ eout, float* __restrict__ rout, float* __restrict__ x, const float* __restrict__ emid,
-                                                 const float* __restrict__ r, const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float w, int zchunk,
-                                                 double* __restrict__ part, float* __restrict__ pmax) {
+                                                    const float* __restrict__ r, const float* __restrict__ L, float w, int zchunk,
+                                                    double* __restrict__ part, float* __restrict__ pmax) {
   __shared__ float sA[2][ZT_LDS];   // ϵ_mid of the newest plane                 (neighbours of sweep 3 one step later)
   __shared__ float sB[2][ZT_LDS];   // plane K-1 after sweep 3                   (neighbours of sweep 4 one step later)
   __shared__ float sC[2][ZT_LDS];   // plane K-2 after sweep 4 = final ϵ         (neighbours of increment! one step later)
@@ -172,31 +183,32 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__
   for (int q = threadIdx.x; q < ZT_LDS; q += ZT_N) { sA[0][q] = 0.f; sA[1][q] = 0.f; sB[0][q] = 0.f; sB[1][q] = 0.f; sC[0][q] = 0.f; sC[1][q] = 0.f; }
   const float* __restrict__ Lx = L; const float* __restrict__ Ly = L + g.cs; const float* __restrict__ Lz = L + 2 * g.cs;
   float e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0;                     // planes K .. K-4
-  float r1 = 0, r2 = 0, r3 = 0, d1 = 0, d2 = 0, lz0 = 0, lz1 = 0, lz2 = 0, lz3 = 0;
+  float r1 = 0, r2 = 0, r3 = 0, d1 = 0, d2 = 0, dg1 = 0, dg2 = 0, dg3 = 0, lz0 = 0, lz1 = 0, lz2 = 0, lz3 = 0;
   float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0, lx3 = 0, lxp3 = 0, ly3 = 0, lyp3 = 0;
   double nsum = 0.0; float nmax = 0.f;
   const int Kbeg = t.ks - 3, Kend = t.ke + 2;
-  float n_e0, n_lz0, n_r1, n_d1, n_lx1, n_lxp1, n_ly1, n_lyp1, n_dg3, n_x3;
+  float n_e0, n_lz0, n_r1, n_lx1, n_lxp1, n_ly1, n_lyp1, n_x3;
   auto fetch = [&](int K) {
     const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
     const long o0 = t.oc + (long)K * g.sz;
     n_e0 = pl0 ? emid[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
     const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
     const long o1 = o0 - g.sz;
-    n_r1 = pl1 ? r[o1] : 0.f; n_d1 = pl1 ? iD[o1] : 0.f;
+    n_r1 = pl1 ? r[o1] : 0.f;
     n_lx1 = pl1 ? Lx[o1] : 0.f; n_lxp1 = pl1 ? Lx[o1 + 1] : 0.f; n_ly1 = pl1 ? Ly[o1] : 0.f; n_lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
     const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
-    const long o3 = o0 - 3 * g.sz;
-    n_dg3 = pl3 ? Dg[o3] : 0.f; n_x3 = pl3 ? x[o3] : 0.f;
+    n_x3 = pl3 ? x[o0 - 3 * g.sz] : 0.f;
   };
   fetch(Kbeg);
   for (int K = Kbeg; K <= Kend; K++) {
-    e4 = e3; e3 = e2; e2 = e1; e1 = e0; r3 = r2; r2 = r1; d2 = d1; lz3 = lz2; lz2 = lz1; lz1 = lz0;
+    e4 = e3; e3 = e2; e2 = e1; e1 = e0; r3 = r2; r2 = r1; d2 = d1; dg3 = dg2; dg2 = dg1; lz3 = lz2; lz2 = lz1; lz1 = lz0;
     lx3 = lx2; lxp3 = lxp2; ly3 = ly2; lyp3 = lyp2; lx2 = lx1; lxp2 = lxp1; ly2 = ly1; lyp2 = lyp1;
-    e0 = n_e0; lz0 = n_lz0; r1 = n_r1; d1 = n_d1; lx1 = n_lx1; lxp1 = n_lxp1; ly1 = n_ly1; lyp1 = n_lyp1;
-    const float dg3 = n_dg3, x3 = n_x3;
+    e0 = n_e0; lz0 = n_lz0; r1 = n_r1; lx1 = n_lx1; lxp1 = n_lxp1; ly1 = n_ly1; lyp1 = n_lyp1;
+    const float x3 = n_x3;
     if (K < Kend) fetch(K + 1);
     const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    dg1 = pl1 ? diag6(lx1, lxp1, ly1, lyp1, lz1, lz0) : 0.f;        // D of plane K-1 (its Lz[I+δz] is plane K's Lz)
+    d1 = inv_diag(dg1);
     const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
     const long o3 = t.oc + (long)(K - 3) * g.sz;
     __syncthreads();
@@ -217,7 +229,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__
       const float rn = r3 - w * s;
       rout[o3] = rn;
       x[o3] = x3 + w * e3;
-      eout[o3] = e3;
+      if (EPS) eout[o3] = e3;
       if (NORMS) { const float av = fabsf(rn); nsum += (double)av; nmax = fmaxf(nmax, av); }
     }
     sA[cb][t.li] = e0;
@@ -254,34 +266,34 @@ static int zchunk_for(const GridX& g, int H) {
 }
 // GaussSeidelRB!(it=4,ω): emid and rout are scratch arrays of the level (ghosts zero); on return eps holds the final ϵ,
 // rout the new residual (caller swaps r<->rout) and x is updated in place.
-int gsrb_fused_A(float* emid, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s) {
+int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, hipStream_t s) {
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{};
-  hipLaunchKernelGGL(k_gsrb_A<0>, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, r, L, iD, zc, pa);
+  hipLaunchKernelGGL(k_gsrb_A<0>, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, r, L, zc, pa);
   WL_LAUNCH_CHECK(); return 0;
 }
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
-int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const float* Dg, const float* iD, const GridX& g, const GridX& gc, float w, hipStream_t s) {
+int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, hipStream_t s) {
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
-  ProArgs pa{xc, Dg, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
-  hipLaunchKernelGGL(k_gsrb_A<1>, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, (const float*)r, L, iD, zc, pa);
+  ProArgs pa{xc, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
+  hipLaunchKernelGGL(k_gsrb_A<1>, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, (const float*)r, L, zc, pa);
   WL_LAUNCH_CHECK(); return 0;
 }
-// ws != NULL: also leaves L₁/L∞ of the new residual in ws->res_d[slot_d] / ws->res_f[slot_f] (device)
-int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const float* Dg, const float* iD, const GridX& g, float w,
+// ws != NULL: also leaves L₁/L∞ of the new residual in ws->res_d[slot_d] / ws->res_f[slot_f] (device); eps == NULL: final ϵ not stored
+int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
                  const RedWs* ws, int slot_d, int slot_f, hipStream_t s) {
   const int zc = zchunk_for(g, 3);
   const int nt = ztile_count(g.nx, g.ny, 3), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   const unsigned nb = (unsigned)(8 * per * nch);
-  if (ws && nb <= WL_MAXPART) {
-    hipLaunchKernelGGL(k_gsrb_B<1>, dim3(nb), dim3(ZT_N), 0, s, g, eps, rout, x, emid, r, L, Dg, iD, w, zc, ws->pa, ws->pm);
-    WL_TRY(finalize_sum_max(*ws, (int)nb, slot_d, slot_f, s));
-  } else {
-    hipLaunchKernelGGL(k_gsrb_B<0>, dim3(nb), dim3(ZT_N), 0, s, g, eps, rout, x, emid, r, L, Dg, iD, w, zc, (double*)nullptr, (float*)nullptr);
-    if (ws) WL_TRY(norms_dev(rout, g, *ws, slot_d, slot_f, s));
-  }
+  const bool norms = ws && nb <= WL_MAXPART;
+  double* pa = norms ? ws->pa : nullptr; float* pm = norms ? ws->pm : nullptr;
+#define WL_GB(NF, EF) hipLaunchKernelGGL((k_gsrb_B<NF, EF>), dim3(nb), dim3(ZT_N), 0, s, g, eps, rout, x, emid, r, L, w, zc, pa, pm)
+  if (norms) { if (eps) WL_GB(1, 1); else WL_GB(1, 0); } else { if (eps) WL_GB(0, 1); else WL_GB(0, 0); }
+#undef WL_GB
+  if (norms) WL_TRY(finalize_sum_max(*ws, (int)nb, slot_d, slot_f, s));
+  else if (ws) WL_TRY(norms_dev(rout, g, *ws, slot_d, slot_f, s));
   WL_LAUNCH_CHECK(); return 0;
 }
 }  // namespace wl

@@ -18,6 +18,7 @@ struct wl_mg {
   std::vector<Level> lv;
   std::vector<int16_t> n;   // pois.n :66
   unsigned perdir = 0;
+  bool store_eps = true;    // the blocked smoother also stores the final ϵ (p.ϵ of the reference); the mom_step! composite turns it off
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
   float* slab = nullptr;    // owns r,ϵ,D,iD of every level and L,x,z of the coarse levels
   void* red = nullptr;      // reduction workspace

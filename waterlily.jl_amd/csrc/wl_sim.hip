@@ -361,6 +361,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   s->mg = new wl_mg();
   int rc = s->mg->build(s->p, s->mu0, s->sigma, s->g, desc->perdir_mask, 10, s->comm);   // pois_ctor default  src/WaterLily.jl:97
   if (rc != 0) { delete s; *out = nullptr; return rc; }
+  s->mg->store_eps = false;   // p.ϵ is pure scratch on the time-step path
   *out = s; return 0;
 }
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) { return sim_create_common(out, desc, nullptr); }
@@ -391,6 +392,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   const std::string n(name);
   if (n == "convz") { s->use_convz = value != 0; return 0; }
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
+  if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
