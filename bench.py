@@ -103,7 +103,7 @@ def main():
         return slab.bench_main(args, world, rank, local_rank)
 
     sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
-    for opt in ("convz", "fused_smoother", "fuse_p"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
+    for opt in ("convz", "fused_smoother", "fuse_p", "constl"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
         if os.environ.get("WL_OPT_" + opt) is not None:
             sim.set_option(opt, int(os.environ["WL_OPT_" + opt]))
     for _ in range(args.warmup):
@@ -151,7 +151,8 @@ def main():
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false (BASELINE configs[4] domain on 1 GPU)",
-                   "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1])},
+                   "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1]),
+                   "constant_coefficient_levels": sim.const_levels()},
         "roofline": {"bound": "hbm", "kernel": "k_gsrb_B (finest-level GaussSeidelRB!: colour sweeps 3,4 + increment!, src/Poisson.jl:141-148)",
                      "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                      "bytes_per_cell": BYTES_GS_B, "avg_launch_ms": kb_ms, "launches": prof["gsrb_B"]["launches"],

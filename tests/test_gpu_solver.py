@@ -307,3 +307,26 @@ def test_zmarching_conv_diff_is_bit_identical(w, oracle, dims, body):
         # corrector input went through a pressure solve (reductions): the two HIP paths must still agree exactly
         assert np.array_equal(res[1][k][0], res[0][k][0]) and np.array_equal(res[1][k][1], res[0][k][1]), ("z-march vs gather", k)
         assert np.abs(res[1][k][1] - outo[k][1]).max() < 2e-5
+
+
+@pytest.mark.parametrize("dims", [(64, 32, 48), (32, 32, 32), (128, 64), (20, 36, 24)])
+@pytest.mark.parametrize("fused", [1, 0])
+def test_constant_coefficient_levels_are_bit_identical(w, dims, fused):
+    """NoBody: L, D, iD evaluated from the cell position (wl::ConstL, verified at update!) vs loaded from memory — whole
+    time steps bit for bit, with and without the blocked smoother (semi-coarsened and odd-sized hierarchies included)."""
+    out = {}
+    for constl in (1, 0):
+        U = (1.0,) + (0.0,) * (len(dims) - 1)
+        rng = np.random.default_rng(3)
+        u = np.asfortranarray(rng.uniform(-1, 1, size=tuple(n + 2 for n in dims) + (len(dims),)).astype(np.float32))
+        s = w.FusedSimulation(dims, U, dims[0], U=1, nu=0.01, u0=u)
+        s.set_option("constl", constl); s.set_option("fused_smoother", fused)
+        if constl:
+            assert s.const_levels()[0]
+        else:
+            assert not any(s.const_levels())
+        for _ in range(3):
+            s.mom_step_()
+        out[constl] = (s.field("u"), s.field("p"), list(s.pois_n), list(s.dt))
+    assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

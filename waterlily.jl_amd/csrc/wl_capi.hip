@@ -120,6 +120,12 @@ int wl_mg::update(hipStream_t s) {                                              
     WL_TRY(restrictL_level(*this, l, s));
     WL_TRY(wl::set_diag(lv[l].D, lv[l].iD, lv[l].L, lv[l].x_, s));
   }
+  // constant-coefficient detection (exact, on device): only the levels that run the specialised kernels are checked
+  for (size_t l = 0; l < lv.size(); l++) {
+    lv[l].cl.on = 0;
+    if (use_constl && !perdir && !lv[l].dist && (l == 0 || wl::gsrb_fused_ok(lv[l].x_, perdir, lv[l].dist)))
+      WL_TRY(wl::check_const_L(lv[l].L, lv[l].x_, &lv[l].cl, (int*)(ws.res_f + 7), s));
+  }
   return 0;
 }
 // the deferred `prolongate!; increment!` of level l, executed on its own (when the next smooth! cannot absorb it)
@@ -147,11 +153,11 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     if (p.pend) {
       Level& coarse = lv[(size_t)l + 1];
       p.pend = false;
-      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, s)); }
-      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, s)); }
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
     } else {
-      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.x_, s)); }
-      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, p.x_, w, nws, 2, 1, s)); }
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.x_, p.cl, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
       std::swap(p.r, p.rs);
     }
     if (norms_done) *norms_done = want_norms;
@@ -178,7 +184,7 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
   {
     ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
     if (!perdir && !fine.dist) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
-      WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, s));
+      WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s));
       std::swap(fine.r, fine.eps);
     } else {
       WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
@@ -379,6 +385,7 @@ float* wl_mg_level_field(const wl_mg* mg, int l, const char* name) {
   return nullptr;
 }
 int wl_mg_smooth(wl_mg* mg, int l, int it, float w, void* st) { WL_CHECK(l >= 0 && l < (int)mg->lv.size(), "level out of range"); return mg->smooth(l, it <= 0 ? 4 : it, w, wl_stream(st)); }
+int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
 int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }

@@ -160,6 +160,17 @@ struct ProfScope {   // RAII: records start at construction and stop at destruct
 
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {
+// A level whose face coefficients are verified (on device, exact comparison) to be "c[a] inside, 0 on the wall faces":
+// the NoBody hierarchy.  Poisson-side kernels then evaluate L, D, iD instead of loading them (identical bits).
+// Dt/iDt: D and iD of a cell as a function of how many of its two faces per direction are non-wall (index nx+3ny+9nz),
+// computed on the host in set_diag!'s operation order (IEEE: same bits as the device would produce).
+struct ConstL { int on; float c[3]; float Dt[27]; float iDt[27]; };
+#ifdef __HIPCC__
+__device__ __forceinline__ float wl_cl_coef(int Ia, int Na, float c) { return (Ia <= 2 || Ia >= Na) ? 0.f : c; }
+// number of non-wall faces (lower + upper) of the cell with Julia index Ia along a direction of extent Na
+__device__ __forceinline__ int wl_cl_cnt(int Ia, int Na) { return ((Ia <= 2 || Ia >= Na) ? 0 : 1) + ((Ia + 1 <= 2 || Ia + 1 >= Na) ? 0 : 1); }
+#endif
+int check_const_L(const float* L, const GridX& g, ConstL* out, int* dev_flag, hipStream_t s);
 int fill(float* a, float v, size_t n, hipStream_t s);
 int scale(float* a, float s_, size_t n, hipStream_t s);
 int div_scalar(float* a, float s_, size_t n, hipStream_t s);
@@ -174,7 +185,7 @@ int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per,
 int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                   float dt, float pre, float post, hipStream_t s);
+                   float dt, float pre, float post, const ConstL& cl, hipStream_t s);
 int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 bool conv_z_ok(const GridX& g, unsigned per);
 int conv_diff_z(float* f, const float* u_adv, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, int scheme, float dt, float pre, float post, hipStream_t s);
@@ -192,8 +203,8 @@ int mult(float* z, const float* L, const float* D, const float* x, const GridX& 
 int residual(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s);
 int residual_part(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s);
 int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s);
-int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws, hipStream_t s);
-int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, hipStream_t s);
+int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s);
+int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s);
 // computes L₁/L∞ of r into ws.res_d[slot_d], ws.res_f[slot_f] (device) — ghosts of r are zero by construction
 int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 int increment(float* r, float* x, const float* eps, const float* L, const float* D, const GridX& g, float w, hipStream_t s);
@@ -201,13 +212,13 @@ int jacobi(float* eps, float* r, float* x, const float* L, const float* D, const
 int gs_init(float* eps, const float* r, const float* iD, const GridX& g, hipStream_t s);
 int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const GridX& g, int k0, hipStream_t s);
 int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s);
-int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, hipStream_t s);
+int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s);
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
-int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, hipStream_t s);
-int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, hipStream_t s);
+int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s);
+int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s);
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
-                 const RedWs* ws, int slot_d, int slot_f, hipStream_t s);
+                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
 int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStream_t s);
 int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s);
 int prolongate(float* a, const GridX& gf, const float* b, const GridX& gc, hipStream_t s);

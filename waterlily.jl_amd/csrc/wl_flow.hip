@@ -133,7 +133,7 @@ __device__ __forceinline__ float face_flux(float U, float t0, float t1, float t2
 // PER = 0: no periodic direction (no wrapped addresses, no branches at all); IDX = int when every component offset fits 31 bits
 // FUSE = 1 appends BDIM! for the NoBody case (μ₁≡0, V≡0; src/Flow.jl:176-180 + the folded scale_u!):
 //   f = u⁰ + Δt·r (all cells) ; u_out = (u·pre + μ₀·f)·post (interior).  u_out must not alias the advecting field u.
-struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre, post; int scale_after; };
+struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre, post; int scale_after; int cl_on; float cl_c[3]; };
 // XSH = 1 (non-periodic only): the flux through a cell's +x face is its x-neighbour's lower-face flux, fetched from lane+1
 // by a wave shuffle instead of being recomputed (3 of the 18 fluxes per cell).  Waves then overlap by one lane: 63 cells
 // per wave, the last lane only feeds lane 62.
@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, fl
       const float fn = bd.u0[oa] + bd.dt * out[a] - 0.f;
       r[oa] = fn;
       if (in) {
-        const float xx = (0.f / 2 + 0.f) + bd.mu0[oa] * fn;
+        const float m0 = bd.cl_on ? wl::wl_cl_coef(I[a], N[a], bd.cl_c[a]) : bd.mu0[oa];     // μ₀ on a verified NoBody field
+        const float xx = (0.f / 2 + 0.f) + m0 * fn;
         float un = (bd.pre == 0.f) ? xx : (u[oa] * bd.pre + xx);
         if (bd.scale_after) un = un * bd.post;
         bd.uout[oa] = un;
@@ -560,7 +561,7 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   const long nbx = xsh ? (g.sz + 251) / 252 : 0;
   const dim3 grid = xsh ? dim3((unsigned)(8L * ((nbx + 7) >> 3) * (klast - kfirst))) : wl_plane_grid(g, klast - kfirst);
   const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
-  BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0};
+  BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0, 0, {0.f, 0.f, 0.f}};
   const BdimArgs ba = bd ? *bd : b0;
 #define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \
   do { if (xsh) hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF, 1 - PERF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba); \
@@ -603,9 +604,9 @@ int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, 
 }
 // conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: f and u_out written, u_out must not alias u_adv
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                   float dt, float pre, float post, hipStream_t s) {
+                   float dt, float pre, float post, const ConstL& cl, hipStream_t s) {
   if (u_out == u_adv) { wl_set_error("conv_diff_bdim: output aliases the advecting field"); return WL_EINVAL; }
-  BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0};
+  BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, cl.on, {cl.c[0], cl.c[1], cl.c[2]}};
   return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
 }
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s) {

@@ -88,6 +88,10 @@ __device__ __forceinline__ float diag6(float lx, float lxp, float ly, float lyp,
   return s;
 }
 __device__ __forceinline__ float inv_diag(float d) { return (d == 0.f) ? d : 1.0f / d; }
+// Constant-coefficient levels (wl::ConstL, verified on device by wl::check_const_L at update!): L[I,a] depends only on the
+// Julia index of I along a — zero on the wall faces (index 1, 2 and N, BC!(μ₀,0) of src/Flow.jl:145 and
+// src/MultiLevelPoisson.jl:47), the constant c_a elsewhere — so the kernels evaluate it instead of loading 12 B/cell.
+__device__ __forceinline__ float cl_coef(int Ia, int Na, float c) { return (Ia <= 2 || Ia >= Na) ? 0.f : c; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // kernel A.  PRO = 1 prepends the Vcycle!'s `prolongate!(ϵ,x_c); increment!(ω)` (src/MultiLevelPoisson.jl:99-100) as one
@@ -97,8 +101,8 @@ __device__ __forceinline__ float inv_diag(float d) { return (d == 0.f) ? d : 1.0
 struct ProArgs { const float* xc; float* x; float* rnew; GridX gc; int cx, cy, cz; float w; };
 __device__ __forceinline__ int dwn(int i, int c) { return c ? (i + 1) / 2 : i; }   // down(I,c), 0-based   :7
 
-template <int PRO>
-__global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__ emid, const float* __restrict__ r, const float* __restrict__ L, int zchunk, ProArgs pa) {
+template <int PRO, int CL>
+__global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__ emid, const float* __restrict__ r, const float* __restrict__ L, int zchunk, ProArgs pa, wl::ConstL cl) {
   __shared__ float sA[2][ZT_LDS];   // ϵ⁰ of the newest plane           (x-y neighbours of sweep 1 one step later)
   __shared__ float sB[2][ZT_LDS];   // ϵ after sweep 1 of plane K-1     (x-y neighbours of sweep 2 one step later)
   const ZTile t = ztile<2>(g, zchunk);
@@ -117,15 +121,25 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
     c00 = dwn(t.i, pa.cx) + cj; cxm = dwn(t.i - 1, pa.cx) + cj; cxp = dwn(t.i + 1, pa.cx) + cj;
     cym = dwn(t.i, pa.cx) + (long)dwn(t.j - 1, pa.cy) * pa.gc.sy; cyp = dwn(t.i, pa.cx) + (long)dwn(t.j + 1, pa.cy) * pa.gc.sy;
   }
+  // in-plane coefficients of this column on a constant-coefficient level (same for every plane)
+  const float kx = CL ? cl_coef(t.i + 1, g.nx, cl.c[0]) : 0.f, kxp = CL ? cl_coef(t.i + 2, g.nx, cl.c[0]) : 0.f;
+  const float ky = CL ? cl_coef(t.j + 1, g.ny, cl.c[1]) : 0.f, kyp = CL ? cl_coef(t.j + 2, g.ny, cl.c[1]) : 0.f;
   // operands of the NEXT step are fetched one plane ahead so that their latency overlaps this step's barrier and arithmetic
-  float n_r0, n_lz0, n_lzp, n_lx, n_lxp, n_ly, n_lyp;
+  float n_r0, n_lz0 = 0, n_lzp = 0, n_lx = 0, n_lxp = 0, n_ly = 0, n_lyp = 0;
   auto fetch = [&](int K) {
     const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
     const long o0 = t.oc + (long)K * g.sz;
-    n_r0 = pl0 ? r[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
+    n_r0 = pl0 ? r[o0] : 0.f;
     const bool pll = t.inter && K >= g.k0 && K < g.k1;           // interior cell of plane K: its six face coefficients
-    n_lx = pll ? Lx[o0] : 0.f; n_lxp = pll ? Lx[o0 + 1] : 0.f; n_ly = pll ? Ly[o0] : 0.f; n_lyp = pll ? Ly[o0 + g.sy] : 0.f;
-    n_lzp = pll ? Lz[o0 + g.sz] : 0.f;
+    if (CL) {
+      n_lz0 = pl0 ? cl_coef(g.gk + K + 1, g.gnz, cl.c[2]) : 0.f;
+      n_lx = pll ? kx : 0.f; n_lxp = pll ? kxp : 0.f; n_ly = pll ? ky : 0.f; n_lyp = pll ? kyp : 0.f;
+      n_lzp = pll ? cl_coef(g.gk + K + 2, g.gnz, cl.c[2]) : 0.f;
+    } else {
+      n_lz0 = pl0 ? Lz[o0] : 0.f;
+      n_lx = pll ? Lx[o0] : 0.f; n_lxp = pll ? Lx[o0 + 1] : 0.f; n_ly = pll ? Ly[o0] : 0.f; n_lyp = pll ? Ly[o0 + g.sy] : 0.f;
+      n_lzp = pll ? Lz[o0 + g.sz] : 0.f;
+    }
   };
   fetch(Kbeg);
   for (int K = Kbeg; K <= Kend; K++) {
@@ -171,10 +185,10 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
 // kernel B.  NORMS = 1 also reduces L₁ = Σ|r'| and L∞ = max|r'| of the new residual (src/Poisson.jl:190-191) per workgroup;
 // EPS = 1 stores the final ϵ (p.ϵ of the reference; nothing on the path reads it again).
 // ------------------------------------------------------------------------------------------------------------------
-template <int NORMS, int EPS>
+template <int NORMS, int EPS, int CL>
 __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__ eout, float* __restrict__ rout, float* __restrict__ x, const float* __restrict__ emid,
                                                     const float* __restrict__ r, const float* __restrict__ L, float w, int zchunk,
-                                                    double* __restrict__ part, float* __restrict__ pmax) {
+                                                    double* __restrict__ part, float* __restrict__ pmax, wl::ConstL cl) {
   __shared__ float sA[2][ZT_LDS];   // ϵ_mid of the newest plane                 (neighbours of sweep 3 one step later)
   __shared__ float sB[2][ZT_LDS];   // plane K-1 after sweep 3                   (neighbours of sweep 4 one step later)
   __shared__ float sC[2][ZT_LDS];   // plane K-2 after sweep 4 = final ϵ         (neighbours of increment! one step later)
@@ -187,15 +201,23 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__
   float lx1 = 0, lxp1 = 0, ly1 = 0, lyp1 = 0, lx2 = 0, lxp2 = 0, ly2 = 0, lyp2 = 0, lx3 = 0, lxp3 = 0, ly3 = 0, lyp3 = 0;
   double nsum = 0.0; float nmax = 0.f;
   const int Kbeg = t.ks - 3, Kend = t.ke + 2;
-  float n_e0, n_lz0, n_r1, n_lx1, n_lxp1, n_ly1, n_lyp1, n_x3;
+  const float kx = CL ? cl_coef(t.i + 1, g.nx, cl.c[0]) : 0.f, kxp = CL ? cl_coef(t.i + 2, g.nx, cl.c[0]) : 0.f;
+  const float ky = CL ? cl_coef(t.j + 1, g.ny, cl.c[1]) : 0.f, kyp = CL ? cl_coef(t.j + 2, g.ny, cl.c[1]) : 0.f;
+  float n_e0, n_lz0 = 0, n_r1, n_lx1 = 0, n_lxp1 = 0, n_ly1 = 0, n_lyp1 = 0, n_x3;
   auto fetch = [&](int K) {
     const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
     const long o0 = t.oc + (long)K * g.sz;
-    n_e0 = pl0 ? emid[o0] : 0.f; n_lz0 = pl0 ? Lz[o0] : 0.f;
+    n_e0 = pl0 ? emid[o0] : 0.f;
     const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
     const long o1 = o0 - g.sz;
     n_r1 = pl1 ? r[o1] : 0.f;
-    n_lx1 = pl1 ? Lx[o1] : 0.f; n_lxp1 = pl1 ? Lx[o1 + 1] : 0.f; n_ly1 = pl1 ? Ly[o1] : 0.f; n_lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+    if (CL) {
+      n_lz0 = pl0 ? cl_coef(g.gk + K + 1, g.gnz, cl.c[2]) : 0.f;
+      n_lx1 = pl1 ? kx : 0.f; n_lxp1 = pl1 ? kxp : 0.f; n_ly1 = pl1 ? ky : 0.f; n_lyp1 = pl1 ? kyp : 0.f;
+    } else {
+      n_lz0 = pl0 ? Lz[o0] : 0.f;
+      n_lx1 = pl1 ? Lx[o1] : 0.f; n_lxp1 = pl1 ? Lx[o1 + 1] : 0.f; n_ly1 = pl1 ? Ly[o1] : 0.f; n_lyp1 = pl1 ? Ly[o1 + g.sy] : 0.f;
+    }
     const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
     n_x3 = pl3 ? x[o0 - 3 * g.sz] : 0.f;
   };
@@ -266,31 +288,37 @@ static int zchunk_for(const GridX& g, int H) {
 }
 // GaussSeidelRB!(it=4,ω): emid and rout are scratch arrays of the level (ghosts zero); on return eps holds the final ϵ,
 // rout the new residual (caller swaps r<->rout) and x is updated in place.
-int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, hipStream_t s) {
+int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s) {
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{};
-  hipLaunchKernelGGL(k_gsrb_A<0>, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, r, L, zc, pa);
+  const dim3 grid((unsigned)(8 * per * nch));
+  if (cl.on) hipLaunchKernelGGL((k_gsrb_A<0, 1>), grid, dim3(ZT_N), 0, s, g, emid, r, L, zc, pa, cl);
+  else hipLaunchKernelGGL((k_gsrb_A<0, 0>), grid, dim3(ZT_N), 0, s, g, emid, r, L, zc, pa, cl);
   WL_LAUNCH_CHECK(); return 0;
 }
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
-int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, hipStream_t s) {
+int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s) {
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{xc, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
-  hipLaunchKernelGGL(k_gsrb_A<1>, dim3((unsigned)(8 * per * nch)), dim3(ZT_N), 0, s, g, emid, (const float*)r, L, zc, pa);
+  const dim3 grid((unsigned)(8 * per * nch));
+  if (cl.on) hipLaunchKernelGGL((k_gsrb_A<1, 1>), grid, dim3(ZT_N), 0, s, g, emid, (const float*)r, L, zc, pa, cl);
+  else hipLaunchKernelGGL((k_gsrb_A<1, 0>), grid, dim3(ZT_N), 0, s, g, emid, (const float*)r, L, zc, pa, cl);
   WL_LAUNCH_CHECK(); return 0;
 }
 // ws != NULL: also leaves L₁/L∞ of the new residual in ws->res_d[slot_d] / ws->res_f[slot_f] (device); eps == NULL: final ϵ not stored
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
-                 const RedWs* ws, int slot_d, int slot_f, hipStream_t s) {
+                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {
   const int zc = zchunk_for(g, 3);
   const int nt = ztile_count(g.nx, g.ny, 3), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   const unsigned nb = (unsigned)(8 * per * nch);
   const bool norms = ws && nb <= WL_MAXPART;
   double* pa = norms ? ws->pa : nullptr; float* pm = norms ? ws->pm : nullptr;
-#define WL_GB(NF, EF) hipLaunchKernelGGL((k_gsrb_B<NF, EF>), dim3(nb), dim3(ZT_N), 0, s, g, eps, rout, x, emid, r, L, w, zc, pa, pm)
-  if (norms) { if (eps) WL_GB(1, 1); else WL_GB(1, 0); } else { if (eps) WL_GB(0, 1); else WL_GB(0, 0); }
+#define WL_GB(NF, EF, CF) hipLaunchKernelGGL((k_gsrb_B<NF, EF, CF>), dim3(nb), dim3(ZT_N), 0, s, g, eps, rout, x, emid, r, L, w, zc, pa, pm, cl)
+#define WL_GB2(NF, EF) do { if (cl.on) WL_GB(NF, EF, 1); else WL_GB(NF, EF, 0); } while (0)
+  if (norms) { if (eps) WL_GB2(1, 1); else WL_GB2(1, 0); } else { if (eps) WL_GB2(0, 1); else WL_GB2(0, 0); }
+#undef WL_GB2
 #undef WL_GB
   if (norms) WL_TRY(finalize_sum_max(*ws, (int)nb, slot_d, slot_f, s));
   else if (ws) WL_TRY(norms_dev(rout, g, *ws, slot_d, slot_f, s));

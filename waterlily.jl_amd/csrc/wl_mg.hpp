@@ -9,6 +9,7 @@ struct wl_mg {
     wl_grid g; GridX x_;
     float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
     float *em = nullptr, *rs = nullptr;   // scratch of the fused smoother: ϵ after sweep 2, new residual (ghosts stay zero)
+    wl::ConstL cl{};                 // constant-coefficient level (verified at update!)
     bool pend = false;       // the V-cycle's prolongate!+increment! of this level is deferred into the next smooth! (fused kernel A)
     bool dist = false;       // z-slab distributed level (halo exchanges) vs replicated on every rank
     GridX view;              // replicated level fed by a distributed parent: the planes of the full array this rank computes
@@ -18,6 +19,7 @@ struct wl_mg {
   std::vector<Level> lv;
   std::vector<int16_t> n;   // pois.n :66
   unsigned perdir = 0;
+  bool use_constl = true;   // allow the constant-coefficient specialisations where the pattern is verified
   bool store_eps = true;    // the blocked smoother also stores the final ϵ (p.ϵ of the reference); the mom_step! composite turns it off
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
   float* slab = nullptr;    // owns r,ϵ,D,iD of every level and L,x,z of the coarse levels

@@ -72,9 +72,9 @@ __global__ void k_residual(GridX g, float* __restrict__ r, const float* __restri
 // mom_project! head (src/Flow.jl:225) + residual! (src/Poisson.jl:92-95) in ONE pass:
 //   z = div(u) ; x_out = x·dt (ALL cells) ; r = iD==0 ? 0 : z − A·(x·dt), with block partial sums of r.
 // x_out ≠ x (neighbours still read the unscaled x; x·dt of a neighbour is recomputed — the same product bit for bit).
-template <int D>
+template <int D, int CL>
 __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict__ xout, float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ u,
-                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part) {
+                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part, wl::ConstL cl) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc = 0.0;
@@ -95,8 +95,15 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
       z[o] = dv;
       // D (and iD==0 ⇔ D==0) recomputed from the face coefficients the stencil loads anyway: same operation order as
       // set_diag! (src/Poisson.jl:43-55), same bits as the stored arrays, 8 B/cell less traffic
-      const float lx = L[o], lxp = L[o + 1], ly = L[g.cs + o], lyp = L[g.cs + o + g.sy];
-      const float lz = (D == 3) ? L[2 * g.cs + o] : 0.f, lzp = (D == 3) ? L[2 * g.cs + o + g.sz] : 0.f;
+      float lx, lxp, ly, lyp, lz = 0.f, lzp = 0.f;
+      if (CL) {
+        lx = wl::wl_cl_coef(i + 1, g.nx, cl.c[0]); lxp = wl::wl_cl_coef(i + 2, g.nx, cl.c[0]);
+        ly = wl::wl_cl_coef(j + 1, g.ny, cl.c[1]); lyp = wl::wl_cl_coef(j + 2, g.ny, cl.c[1]);
+        if (D == 3) { lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]); lzp = wl::wl_cl_coef(g.gk + k + 2, g.gnz, cl.c[2]); }
+      } else {
+        lx = L[o]; lxp = L[o + 1]; ly = L[g.cs + o]; lyp = L[g.cs + o + g.sy];
+        if (D == 3) { lz = L[2 * g.cs + o]; lzp = L[2 * g.cs + o + g.sz]; }
+      }
       float dgv = 0.f;
       dgv -= (lx + lxp);
       dgv -= (ly + lyp);
@@ -114,8 +121,8 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
 // mom_project! tail (src/Flow.jl:227-230): u[I,i] -= L[I,i]·∂ᵢx ; p_out = x/dt (ALL cells), p_out ≠ x
-template <int D>
-__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt) {
+template <int D, int CL>
+__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
@@ -129,6 +136,27 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
   u[o] -= L[o] * (xc - x[o - 1]);
   u[g.cs + o] -= L[g.cs + o] * (xc - x[o - g.sy]);
   if (D == 3) u[2 * g.cs + o] -= L[2 * g.cs + o] * (xc - x[o - g.sz]);
+}
+// exact test of the constant-coefficient pattern over EVERY cell of L (ghosts included): L[I,a] == (I_a ∈ {1,2,N_a} ? 0 : c_a)
+template <int D>
+__global__ void k_check_const_L(GridX g, const float* __restrict__ L, float c0, float c1, float c2, int* __restrict__ flag) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = pz;
+  // slab ranks: planes outside the global array (beyond the physical ghost plane) hold nothing meaningful
+  const int Kj = (D == 3) ? g.gk + k + 1 : 1;
+  if (D == 3 && (Kj < 1 || Kj > g.gnz)) return;
+  const long o = m + (long)k * g.sz;
+  const float c[3] = {c0, c1, c2};
+  const int I[3] = {i + 1, j + 1, Kj};
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
+  bool bad = false;
+  for (int a = 0; a < D; a++) {
+    const float want = (I[a] <= 2 || I[a] >= N[a]) ? 0.f : c[a];
+    bad = bad || (L[(long)a * g.cs + o] != want);
+  }
+  if (bad) atomicOr(flag, 1);
 }
 // deterministic second stage: res_d[slot] = Σ partials
 __global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
@@ -252,6 +280,35 @@ __global__ void k_gs_init_sweep1(GridX g, float* __restrict__ eps, const float* 
 }
 // Jacobi!(it=1,ω): ϵ=r·iD ; r -= ωAϵ ; x += ωϵ in ONE pass.  The new residual goes to `rout` (≠ r: neighbours still read
 // the old r); the caller then swaps its r/ϵ buffers.  36 instead of 12+36 B/cell.                 src/Poisson.jl:111-114
+// constant-coefficient Jacobi!: L, D, iD evaluated from the cell position (wl::ConstL) — 16 instead of 32 B/cell
+template <int D>
+__global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl) {
+  __shared__ float sDt[27], siDt[27];
+  if (threadIdx.x < 27) { sDt[threadIdx.x] = cl.Dt[threadIdx.x]; siDt[threadIdx.x] = cl.iDt[threadIdx.x]; }
+  __syncthreads();
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const int k = g.k0 + pz;
+  const long o = m + (long)k * g.sz;
+  const int I0 = i + 1, I1 = j + 1, I2 = (D == 3) ? g.gk + k + 1 : 3;
+  const int N2 = (D == 3) ? g.gnz : 8;
+  // non-wall face counts of this cell and of its ±1 neighbours along each direction (ghost neighbours: r = 0 there anyway)
+  const int cx0 = wl::wl_cl_cnt(I0, g.nx), cxm = wl::wl_cl_cnt(I0 - 1, g.nx), cxp = wl::wl_cl_cnt(I0 + 1, g.nx);
+  const int cy0 = wl::wl_cl_cnt(I1, g.ny), cym = wl::wl_cl_cnt(I1 - 1, g.ny), cyp = wl::wl_cl_cnt(I1 + 1, g.ny);
+  const int cz0 = (D == 3) ? wl::wl_cl_cnt(I2, N2) : 0, czm = (D == 3) ? wl::wl_cl_cnt(I2 - 1, N2) : 0, czp = (D == 3) ? wl::wl_cl_cnt(I2 + 1, N2) : 0;
+  const float lx = wl::wl_cl_coef(I0, g.nx, cl.c[0]), lxp = wl::wl_cl_coef(I0 + 1, g.nx, cl.c[0]);
+  const float ly = wl::wl_cl_coef(I1, g.ny, cl.c[1]), lyp = wl::wl_cl_coef(I1 + 1, g.ny, cl.c[1]);
+  const float lz = (D == 3) ? wl::wl_cl_coef(I2, N2, cl.c[2]) : 0.f, lzp = (D == 3) ? wl::wl_cl_coef(I2 + 1, N2, cl.c[2]) : 0.f;
+  auto ID = [&](int a, int b, int c) -> float { return siDt[a + 3 * b + 9 * c]; };
+  const float e0 = r[o] * ID(cx0, cy0, cz0);
+  float s = e0 * sDt[cx0 + 3 * cy0 + 9 * cz0];
+  s += ((r[o - 1] * ID(cxm, cy0, cz0)) * lx + (r[o + 1] * ID(cxp, cy0, cz0)) * lxp);
+  s += ((r[o - g.sy] * ID(cx0, cym, cz0)) * ly + (r[o + g.sy] * ID(cx0, cyp, cz0)) * lyp);
+  if (D == 3) s += ((r[o - g.sz] * ID(cx0, cy0, czm)) * lz + (r[o + g.sz] * ID(cx0, cy0, czp)) * lzp);
+  rout[o] = r[o] - w * s;
+  x[o] = x[o] + w * e0;
+}
 template <int D>
 __global__ void k_jacobi_pp(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, const float* __restrict__ L,
                             const float* __restrict__ Dg, const float* __restrict__ iD, float w) {
@@ -400,15 +457,46 @@ int residual_part(float* r, const float* x, const float* z, const float* L, cons
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
-int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* Dg, const float* iD, const GridX& g, float dt, const RedWs& ws, hipStream_t s) {
+#define DSEL2(D, CLF, KERN, ...)                                                                                     \
+  do { if ((D) == 3) { if (CLF) hipLaunchKernelGGL((KERN<3, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERN<3, 0>), __VA_ARGS__); } \
+       else { if (CLF) hipLaunchKernelGGL((KERN<2, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERN<2, 0>), __VA_ARGS__); } } while (0)
+int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* Dg, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s) {
   dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.nz));
-  DSEL(g.D, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa);
+  DSEL2(g.D, cl.on, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa, cl);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
-int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, hipStream_t s) {
-  DSEL(g.D, k_project_unscale, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt);
+int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s) {
+  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl);
   WL_LAUNCH_CHECK(); return 0;
+}
+// host-synchronising (update! time only): reads one interior face value per component, then verifies the whole array on device
+int check_const_L(const float* L, const GridX& g, ConstL* out, int* dev_flag, hipStream_t s) {
+  out->on = 0; out->c[0] = out->c[1] = out->c[2] = 0.f;
+  if (g.nx < 5 || g.ny < 5 || (g.D == 3 && (g.k1 - g.k0) < 1)) return 0;
+  // a cell whose lower faces are not wall faces in any direction: Julia index 3 in x,y and (globally) >= 3 in z
+  int kk = (g.D == 3) ? g.k0 + ((g.gk + g.k0 + 1 >= 3) ? 0 : 1) : 0;
+  if (g.D == 3 && (kk >= g.k1 || g.gk + kk + 1 >= g.gnz)) return 0;
+  const long o = 2 + 2 * g.sy + (long)kk * g.sz;
+  float c[3] = {0.f, 0.f, 0.f};
+  for (int a = 0; a < g.D; a++) WL_HIP(hipMemcpyAsync(&c[a], L + (long)a * g.cs + o, sizeof(float), hipMemcpyDeviceToHost, s));
+  WL_HIP(hipMemsetAsync(dev_flag, 0, sizeof(int), s));
+  WL_HIP(hipStreamSynchronize(s));
+  DSEL(g.D, k_check_const_L, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, L, c[0], c[1], c[2], dev_flag);
+  int bad = 1;
+  WL_HIP(hipMemcpyAsync(&bad, dev_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  WL_HIP(hipStreamSynchronize(s));
+  if (!bad) {
+    out->on = 1; for (int a = 0; a < 3; a++) out->c[a] = c[a];
+    for (int nz = 0; nz < 3; nz++) for (int ny = 0; ny < 3; ny++) for (int nx = 0; nx < 3; nx++) {
+      // pair sums lower+upper face: 2 non-wall faces c+c, one c+0 (or 0+c: same value), none 0+0
+      const float px = nx == 2 ? c[0] + c[0] : (nx == 1 ? c[0] + 0.f : 0.f), py = ny == 2 ? c[1] + c[1] : (ny == 1 ? c[1] + 0.f : 0.f);
+      const float pzv = nz == 2 ? c[2] + c[2] : (nz == 1 ? c[2] + 0.f : 0.f);
+      float d = 0.f; d -= px; d -= py; if (g.D == 3) d -= pzv;                    // set_diag! order  src/Poisson.jl:49-55
+      out->Dt[nx + 3 * ny + 9 * nz] = d; out->iDt[nx + 3 * ny + 9 * nz] = (d == 0.f) ? d : 1.0f / d;
+    }
+  }
+  return 0;
 }
 int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s) {
   hipLaunchKernelGGL(k_mean_shift, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}));
@@ -448,8 +536,9 @@ int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, 
   DSEL(g.D, k_gs_init_sweep1, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, L, iD);
   WL_LAUNCH_CHECK(); return 0;
 }
-int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, hipStream_t s) {
-  DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
+int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s) {
+  if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
+  else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
   WL_LAUNCH_CHECK(); return 0;
 }
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {

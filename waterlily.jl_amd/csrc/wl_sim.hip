@@ -219,7 +219,7 @@ struct wl_sim {
       if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
         WL_TRY(wl::conv_diff_z(f, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
         WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
-      } else WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, s));
+      } else WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, mg->lv[0].cl, s));
     } else {
       { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
       WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
@@ -234,7 +234,7 @@ struct wl_sim {
         if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
           WL_TRY(wl::conv_diff_z(f, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
           WL_TRY(wl::conv_q1(sigma, u, G, d.nu, d.perdir_mask, d.scheme, s));
-        } else WL_TRY(wl::conv_diff_bdim(f, u, sigma, u0, mu0, us, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 1.f, 0.5f, s)); }
+        } else WL_TRY(wl::conv_diff_bdim(f, u, sigma, u0, mu0, us, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 1.f, 0.5f, mg->lv[0].cl, s)); }
       std::swap(u, us);
       return bc_u(s);
     }
@@ -247,11 +247,11 @@ struct wl_sim {
     if (ps && use_fuse_p && !d.perdir_mask && !comm) {
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
-      { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(sigma, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, s)); }
+      { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(sigma, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s)); }
       std::swap(p, ps); l0.x = p;
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
-      WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, s));
+      WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
       std::swap(p, ps); l0.x = p;
       return bc_u(s);
     }
@@ -393,6 +393,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "convz") { s->use_convz = value != 0; return 0; }
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
+  if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }

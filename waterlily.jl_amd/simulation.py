@@ -158,6 +158,11 @@ class FusedSimulation:
     def nlevels(self):
         return lib().wl_mg_nlevels(lib().wl_sim_pois(self._h))
 
+    def const_levels(self):
+        """per level: was L verified to be 'constant inside, zero on wall faces' (constant-coefficient kernels in use)"""
+        mg = lib().wl_sim_pois(self._h)
+        return [bool(lib().wl_mg_level_is_const(mg, l)) for l in range(self.nlevels())]
+
     def measure_sphere_(self, center, R, eps=1.0):
         """measure!(sim) for AutoBody(|x-c|-R): closed form on device + update!(pois)"""
         c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
