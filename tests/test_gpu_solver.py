@@ -330,3 +330,79 @@ def test_constant_coefficient_levels_are_bit_identical(w, dims, fused):
         out[constl] = (s.field("u"), s.field("p"), list(s.pois_n), list(s.dt))
     assert out[0][2] == out[1][2] and out[0][3] == out[1][3]
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+def _const_L(N, c):
+    L = np.zeros(N + (3,), dtype=np.float32, order="F")
+    for a in range(3):
+        L[..., a] = np.float32(c[a])
+    return L
+
+
+@pytest.mark.parametrize("N,c", [((66, 34, 18), (1, 1, 1)), ((130, 130, 34), (1, 1, 1)), ((70, 46, 35), (0.5, 1.0, 0.25)), ((514, 66, 20), (1, 2, 4)),
+                                 ((66, 34, 130), (1, 1, 1)), ((194, 66, 12), (2, 1, 1))])
+@pytest.mark.parametrize("omega", [1.0, 0.73])
+def test_pair_smoother_is_bit_identical(w, oracle, N, c, omega):
+    """constant-coefficient level: two-cells-per-thread blocked GaussSeidelRB! (wl_fused2.hip) vs the one-cell blocked kernels
+    vs one kernel per pass vs the oracle — ϵ, r, x bit for bit (tiles ending on the boundary, several z-chunks, quirk Q4,
+    anisotropic coefficients as on semi-coarsened levels)."""
+    import ctypes as C
+    rng = np.random.default_rng(47)
+    L = _const_L(N, c)
+    oracle.BC(L, (0, 0, 0))
+    x0 = np.asfortranarray(rng.uniform(-1, 1, size=N).astype(np.float32))
+    z, r0 = F(N), F(N)
+    r0[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(n - 2 for n in N)).astype(np.float32)
+    try:
+        po = oracle.MultiLevelPoisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    except AssertionError:
+        po = oracle.Poisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    po.field("r", 0)[...] = r0
+    po.GaussSeidelRB(0, 4, omega)
+    lib = w.lib()
+    res = {}
+    for tag, fused, pair in (("pair", True, True), ("one", True, False), ("passes", False, False)):
+        xg, Lg, zg = w.to_device(x0), w.to_device(L), w.to_device(z)
+        try:
+            pg = w.MultiLevelPoisson(xg, Lg, zg)
+        except AssertionError:
+            pytest.skip("shape has fewer than 3 levels")
+        assert pg.level_is_const(0)
+        pg.set_fused(fused, pair)
+        w._lib.check(lib.wl_h2d(lib.wl_mg_level_field(pg._h, 0, b"r"), r0.ctypes.data_as(C.c_void_p), r0.nbytes, w.core.stream()))
+        pg.smooth_(0, 4, omega)
+        res[tag] = (pg.levels[0].eps, pg.levels[0].r, w.to_host(xg))
+        pg.set_fused(True, True)
+    for name, k in (("eps", 0), ("r", 1), ("x", 2)):
+        assert np.array_equal(res["pair"][k], po.field(name, 0)), ("pair vs oracle", name)
+        assert np.array_equal(res["pair"][k], res["one"][k]), ("pair vs one-cell blocked", name)
+        assert np.array_equal(res["pair"][k], res["passes"][k]), ("pair vs passes", name)
+
+
+@pytest.mark.parametrize("N", [(130, 66, 34), (66, 66, 66), (98, 50, 26), (258, 34, 18)])
+def test_pair_vcycle_with_fused_prolongation_is_bit_identical(w, oracle, N):
+    """Vcycle! + the solver's post-smoothing on a NoBody hierarchy: prolongate!+increment! folded into pair kernel A,
+    L₁/L∞ from pair kernel B; r and x of every level bit for bit against the oracle and the unfused path."""
+    import ctypes as C
+    rng = np.random.default_rng(53)
+    L = _const_L(N, (1, 1, 1))
+    oracle.BC(L, (0, 0, 0))
+    x0, z, r0 = F(N), F(N), F(N)
+    r0[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(n - 2 for n in N)).astype(np.float32)
+    po = oracle.MultiLevelPoisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    po.field("r", 0)[...] = r0
+    po.Vcycle(0, 0.9); po.GaussSeidelRB(0, 4, 0.9)
+    lib = w.lib()
+    res = {}
+    for tag, fused, pair in (("pair", True, True), ("passes", False, False)):
+        xg, Lg, zg = w.to_device(x0), w.to_device(L), w.to_device(z)
+        pg = w.MultiLevelPoisson(xg, Lg, zg)
+        pg.set_fused(fused, pair)
+        w._lib.check(lib.wl_h2d(lib.wl_mg_level_field(pg._h, 0, b"r"), r0.ctypes.data_as(C.c_void_p), r0.nbytes, w.core.stream()))
+        pg.Vcycle_(0, 0.9); pg.smooth_(0, 4, 0.9)
+        res[tag] = [(pg.levels[l].r, pg.levels[l].x) for l in range(po.nlevels)]
+        pg.set_fused(True, True)
+    for l in range(po.nlevels):
+        for k, name in enumerate(("r", "x")):
+            assert np.array_equal(res["pair"][l][k], po.field(name, l)), ("pair vs oracle", l, name)
+            assert np.array_equal(res["pair"][l][k], res["passes"][l][k]), ("pair vs passes", l, name)

@@ -220,6 +220,13 @@ int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const f
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
                  const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
 int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStream_t s);
+// pair variant of the blocked smoother for constant-coefficient levels (wl_fused2.hip); chosen inside gsrb_fused_* when eligible
+void gsrb_pair_enable(int on);
+bool gsrb_pair_ok(const GridX& g, const ConstL& cl);
+int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s);
+int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s);
+int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
+                const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
 int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s);
 int prolongate(float* a, const GridX& gf, const float* b, const GridX& gc, hipStream_t s);
 int prolong_increment(float* r, float* x, float* eps, const float* xc, const float* L, const float* D, const GridX& gf, const GridX& gc, float w, bool write_eps, hipStream_t s);

@@ -12,6 +12,8 @@
 // Arithmetic (operation order, colour rule, quirk Q4) is exactly that of k_gs_sweep/k_increment ⇒ bit-identical results.
 // Preconditions (checked by the caller): D==3, non-periodic, not a z-slab level, ghost cells of r, iD, ϵ are zero
 // (true for the arrays a wl_mg handle owns), so `r·iD` of a ghost cell reproduces the stored ghost ϵ (=0).
+#include <cstdint>
+
 #include "wl_common.hpp"
 
 #ifndef ZT_X
@@ -288,7 +290,11 @@ static int zchunk_for(const GridX& g, int H) {
 }
 // GaussSeidelRB!(it=4,ω): emid and rout are scratch arrays of the level (ghosts zero); on return eps holds the final ϵ,
 // rout the new residual (caller swaps r<->rout) and x is updated in place.
+static inline bool al8(const void* a, const void* b = nullptr, const void* c = nullptr, const void* d = nullptr, const void* e = nullptr) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 7u) == 0;
+}
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s) {
+  if (gsrb_pair_ok(g, cl) && al8(emid, r)) return gsrb_pair_A(emid, r, g, cl, s);
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{};
@@ -299,6 +305,7 @@ int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, co
 }
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s) {
+  if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s);
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{xc, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
@@ -310,6 +317,7 @@ int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const f
 // ws != NULL: also leaves L₁/L∞ of the new residual in ws->res_d[slot_d] / ws->res_f[slot_f] (device); eps == NULL: final ϵ not stored
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
                  const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {
+  if (gsrb_pair_ok(g, cl) && al8(eps, rout, x, emid, r)) return gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s);
   const int zc = zchunk_for(g, 3);
   const int nt = ztile_count(g.nx, g.ny, 3), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   const unsigned nb = (unsigned)(8 * per * nch);

@@ -171,8 +171,12 @@ class MultiLevelPoisson:
         """smooth!(levels[l];ω) = GaussSeidelRB!   src/MultiLevelPoisson.jl:106"""
         check(lib().wl_mg_smooth(self._h, int(l), int(it), float(w), stream()))
 
-    def set_fused(self, on):
-        check(lib().wl_mg_set_fused(self._h, int(bool(on))))
+    def set_fused(self, on, pair=True):
+        """on: temporally blocked smoother; pair: its two-cells-per-thread variant on constant-coefficient levels"""
+        check(lib().wl_mg_set_fused(self._h, int(bool(on)) | (0 if pair else 4)))
+
+    def level_is_const(self, l):
+        return bool(lib().wl_mg_level_is_const(self._h, l))
 
     def solver_(self, tol=2e-3, itmx=32):
         """solver!(ml;tol,itmx)   :108-128"""
