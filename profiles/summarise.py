@@ -58,11 +58,11 @@ json.dump(summary, open(os.path.join(root, f"{tag}_summary_{size}.json"), "w"), 
 # the figure bench.py reports as roofline.traffic for the dominant kernel
 best = None
 for k, v in traffic.items():
-    if "k_gsrb_B" in k and (best is None or v["hbm_bytes_raw"] > traffic[best]["hbm_bytes_raw"]):
+    if ("k_gsrb_B" in k or "k_gsrb2_B" in k) and (best is None or v["hbm_bytes_raw"] > traffic[best]["hbm_bytes_raw"]):
         best = k
 for k, v in traffic.items():
     if k == best:
-        json.dump({"size": size, "kernel": "k_gsrb_B", "hbm_bytes_per_launch": v["hbm_bytes_fetch_x2"], "raw_bytes_per_launch": v["hbm_bytes_raw"],
+        json.dump({"size": size, "kernel": "k_gsrb2_B" if "k_gsrb2_B" in k else "k_gsrb_B", "hbm_bytes_per_launch": v["hbm_bytes_fetch_x2"], "raw_bytes_per_launch": v["hbm_bytes_raw"],
                    "source": f"profiles/{tag}_summary_{size}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per gfx950 note)"},
                   open(os.path.join(root, "traffic_latest.json"), "w"), indent=1)
 ncell = float(size) ** 3

@@ -67,6 +67,16 @@ static inline dim3 wl_plane_grid(const GridX& g, int nplanes) { return dim3((uns
 #define WL_REDPART 8192
 static inline int wl_red_slots(const GridX& g, int nplanes) { long by = WL_REDPART / (8L * wl_strip_blocks(g)); if (by < 1) by = 1; return (int)(by < nplanes ? by : nplanes); }
 
+// z-marching kernels: every plane slot owns a CONTIGUOUS chunk of planes (z-neighbours stay in registers).  Chunk length:
+// up to 32 planes, shorter on small grids so that a launch still has a few thousand workgroups.
+static inline int wl_march_chunk(const GridX& g, int nplanes) {
+  const long bp = 8L * wl_strip_blocks(g);
+  long c = (long)nplanes * bp / 4096; if (c > 32) c = 32; if (c < 1) c = 1;
+  while ((nplanes + c - 1) / c * bp > 65536 && c < nplanes) c++;      // per-workgroup partials must fit the reduction workspace
+  return (int)c;
+}
+static inline int wl_march_slots(int nplanes, int chunk) { return (nplanes + chunk - 1) / chunk; }
+
 #ifdef __HIPCC__
 // block -> (flattened in-plane index m of this thread, plane slot p); false when the block lies beyond the plane
 __device__ __forceinline__ bool wl_tile(const GridX& g, long& m, int& p) {

@@ -367,15 +367,17 @@ __global__ void k_project(GridX g, float* __restrict__ u, const float* __restric
 }
 // CFL: σ = flux_out on the interior; block max over ALL cells of σ (ghost planes keep stale Φ — quirk Q1)  src/Flow.jl:234-244
 template <int D>
-__global__ void k_cfl(GridX g, const float* __restrict__ u, float* __restrict__ sigma, float* __restrict__ pmax, int kfirst, int klast) {
+__global__ void k_cfl(GridX g, const float* __restrict__ u, float* __restrict__ sigma, float* __restrict__ pmax, int kfirst, int klast, int zchunk) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   float mx = -INFINITY;
-  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j)) {
     const bool inij = interior_ij(g, i, j);
-    for (int k = kfirst + pz; k < klast; k += nsl) {
-      const long o = m + (long)k * g.sz;
+    const int ks = kfirst + pz * zchunk, ke = (ks + zchunk < klast) ? ks + zchunk : klast;   // contiguous planes: u_z[k+1] becomes u_z[k]
+    long o = m + (long)ks * g.sz;
+    float uzk = (D == 3 && inij && ks < ke) ? u[2 * g.cs + o] : 0.f;
+    for (int k = ks; k < ke; k++, o += g.sz) {
+      const float uzkp = (D == 3 && inij && k + 1 < g.nz) ? u[2 * g.cs + o + g.sz] : 0.f;
       bool in = inij;
       if (D == 3) in = in && k >= g.k0 && k < g.k1;
       float s;
@@ -383,10 +385,11 @@ __global__ void k_cfl(GridX g, const float* __restrict__ u, float* __restrict__ 
         s = 0.f;
         s += (fmaxf(0.f, u[o + 1]) + fmaxf(0.f, -u[o]));
         s += (fmaxf(0.f, u[g.cs + o + g.sy]) + fmaxf(0.f, -u[g.cs + o]));
-        if (D == 3) s += (fmaxf(0.f, u[2 * g.cs + o + g.sz]) + fmaxf(0.f, -u[2 * g.cs + o]));
+        if (D == 3) s += (fmaxf(0.f, uzkp) + fmaxf(0.f, -uzk));
         sigma[o] = s;
       } else s = sigma[o];
       mx = fmaxf(mx, s);
+      uzk = uzkp;
     }
   }
   mx = block_max(mx);
@@ -636,8 +639,9 @@ int project(float* u, const float* L, const float* x, const GridX& g, hipStream_
 int cfl_dev(const float* u, float* sigma, const GridX& g, const RedWs& ws, int slot_f, hipStream_t s) {
   int kfirst = 0, klast = 1;
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
-  dim3 grid = wl_plane_grid(g, wl_red_slots(g, klast - kfirst));
-  DSEL(g.D, k_cfl, grid, dim3(WL_BLOCK), 0, s, g, u, sigma, ws.pm, kfirst, klast);
+  const int zc = wl_march_chunk(g, klast - kfirst);
+  dim3 grid = wl_plane_grid(g, wl_march_slots(klast - kfirst, zc));
+  DSEL(g.D, k_cfl, grid, dim3(WL_BLOCK), 0, s, g, u, sigma, ws.pm, kfirst, klast, zc);
   hipLaunchKernelGGL(k_fin_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }

@@ -14,6 +14,8 @@
 // (IEEE addition is commutative, which is all the operand re-pairing relies on).
 // Preconditions (checked by gsrb_pair_ok): everything gsrb_fused_ok needs, plus cl.on, nx even (float2 alignment),
 // and < 2^30 elements per field (32-bit offsets).
+#include <cstdlib>
+
 #include "wl_common.hpp"
 
 #define PT_X 32                      // threads along x (two cells each)
@@ -300,7 +302,8 @@ int g_pair_on = 1;
 int zchunk2(const GridX& g, int HX, int HY) {
   const int nt = ptile_count(g.nx, g.ny, HX, HY);
   const int np = g.k1 - g.k0;
-  int chunks = (1536 + nt - 1) / nt; if (chunks < 1) chunks = 1;
+  static const int target = getenv("WL_PAIR_WGS") ? atoi(getenv("WL_PAIR_WGS")) : 1536;
+  int chunks = target >= 0 ? (target + nt - 1) / nt : (-target) / nt; if (chunks < 1) chunks = 1;
   int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
   return zc;
 }

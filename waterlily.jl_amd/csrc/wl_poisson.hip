@@ -74,47 +74,58 @@ __global__ void k_residual(GridX g, float* __restrict__ r, const float* __restri
 // x_out ≠ x (neighbours still read the unscaled x; x·dt of a neighbour is recomputed — the same product bit for bit).
 template <int D, int CL>
 __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict__ xout, float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ u,
-                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part, wl::ConstL cl) {
+                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part, wl::ConstL cl, int zchunk) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc = 0.0;
-  const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j)) {
     const bool inij = interior_ij(g, i, j);
-    for (int k = pz; k < g.nz; k += nsl) {
-      const long o = m + (long)k * g.sz;
-      const float xs = x[o] * dt;
+    // this slot marches over planes [ks,ke): x[k-1], x[k], x[k+1] and u_z[k], u_z[k+1] live in registers
+    const int ks = pz * zchunk, ke = (ks + zchunk < g.nz) ? ks + zchunk : g.nz;
+    long o = m + (long)ks * g.sz;
+    float xkm = (D == 3 && ks > 0) ? x[o - g.sz] : 0.f, xk = (ks < ke) ? x[o] : 0.f;
+    float uzk = (D == 3 && inij && ks < ke) ? u[2 * g.cs + o] : 0.f;
+    float lx = 0.f, lxp = 0.f, ly = 0.f, lyp = 0.f;
+    if (CL) {
+      lx = wl::wl_cl_coef(i + 1, g.nx, cl.c[0]); lxp = wl::wl_cl_coef(i + 2, g.nx, cl.c[0]);
+      ly = wl::wl_cl_coef(j + 1, g.ny, cl.c[1]); lyp = wl::wl_cl_coef(j + 2, g.ny, cl.c[1]);
+    }
+    for (int k = ks; k < ke; k++, o += g.sz) {
+      const bool up = D == 3 && k + 1 < g.nz;
+      const float xkp = up ? x[o + g.sz] : 0.f;
+      const float uzkp = (up && inij) ? u[2 * g.cs + o + g.sz] : 0.f;
+      const float xs = xk * dt;
       xout[o] = xs;
       bool in = inij;
       if (D == 3) in = in && k >= g.k0 && k < g.k1;
-      if (!in) continue;
-      float dv = 0.f;
-      dv += u[o + 1] - u[o];
-      dv += u[g.cs + o + g.sy] - u[g.cs + o];
-      if (D == 3) dv += u[2 * g.cs + o + g.sz] - u[2 * g.cs + o];
-      z[o] = dv;
-      // D (and iD==0 ⇔ D==0) recomputed from the face coefficients the stencil loads anyway: same operation order as
-      // set_diag! (src/Poisson.jl:43-55), same bits as the stored arrays, 8 B/cell less traffic
-      float lx, lxp, ly, lyp, lz = 0.f, lzp = 0.f;
-      if (CL) {
-        lx = wl::wl_cl_coef(i + 1, g.nx, cl.c[0]); lxp = wl::wl_cl_coef(i + 2, g.nx, cl.c[0]);
-        ly = wl::wl_cl_coef(j + 1, g.ny, cl.c[1]); lyp = wl::wl_cl_coef(j + 2, g.ny, cl.c[1]);
-        if (D == 3) { lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]); lzp = wl::wl_cl_coef(g.gk + k + 2, g.gnz, cl.c[2]); }
-      } else {
-        lx = L[o]; lxp = L[o + 1]; ly = L[g.cs + o]; lyp = L[g.cs + o + g.sy];
-        if (D == 3) { lz = L[2 * g.cs + o]; lzp = L[2 * g.cs + o + g.sz]; }
+      if (in) {
+        float dv = 0.f;
+        dv += u[o + 1] - u[o];
+        dv += u[g.cs + o + g.sy] - u[g.cs + o];
+        if (D == 3) dv += uzkp - uzk;
+        z[o] = dv;
+        // D (and iD==0 ⇔ D==0) recomputed from the face coefficients the stencil needs anyway: same operation order as
+        // set_diag! (src/Poisson.jl:43-55), same bits as the stored arrays, 8 B/cell less traffic
+        float lz = 0.f, lzp = 0.f;
+        if (CL) {
+          if (D == 3) { lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]); lzp = wl::wl_cl_coef(g.gk + k + 2, g.gnz, cl.c[2]); }
+        } else {
+          lx = L[o]; lxp = L[o + 1]; ly = L[g.cs + o]; lyp = L[g.cs + o + g.sy];
+          if (D == 3) { lz = L[2 * g.cs + o]; lzp = L[2 * g.cs + o + g.sz]; }
+        }
+        float dgv = 0.f;
+        dgv -= (lx + lxp);
+        dgv -= (ly + lyp);
+        if (D == 3) dgv -= (lz + lzp);
+        float s = xs * dgv;
+        s += ((x[o - 1] * dt) * lx + (x[o + 1] * dt) * lxp);
+        s += ((x[o - g.sy] * dt) * ly + (x[o + g.sy] * dt) * lyp);
+        if (D == 3) s += ((xkm * dt) * lz + (xkp * dt) * lzp);
+        const float v = (dgv == 0.f) ? 0.f : dv - s;
+        r[o] = v;
+        acc += (double)v;
       }
-      float dgv = 0.f;
-      dgv -= (lx + lxp);
-      dgv -= (ly + lyp);
-      if (D == 3) dgv -= (lz + lzp);
-      float s = xs * dgv;
-      s += ((x[o - 1] * dt) * lx + (x[o + 1] * dt) * lxp);
-      s += ((x[o - g.sy] * dt) * ly + (x[o + g.sy] * dt) * lyp);
-      if (D == 3) s += ((x[o - g.sz] * dt) * lz + (x[o + g.sz] * dt) * lzp);
-      const float v = (dgv == 0.f) ? 0.f : dv - s;
-      r[o] = v;
-      acc += (double)v;
+      xkm = xk; xk = xkp; uzk = uzkp;
     }
   }
   acc = block_sum(acc);
@@ -122,20 +133,28 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
 }
 // mom_project! tail (src/Flow.jl:227-230): u[I,i] -= L[I,i]·∂ᵢx ; p_out = x/dt (ALL cells), p_out ≠ x
 template <int D, int CL>
-__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl) {
+__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl, int zchunk) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
-  const int k = pz;
-  const long o = m + (long)k * g.sz;
-  const float xc = x[o];
-  pout[o] = xc / dt;
-  bool in = interior_ij(g, i, j);
-  if (D == 3) in = in && k >= g.k0 && k < g.k1;
-  if (!in) return;
-  u[o] -= L[o] * (xc - x[o - 1]);
-  u[g.cs + o] -= L[g.cs + o] * (xc - x[o - g.sy]);
-  if (D == 3) u[2 * g.cs + o] -= L[2 * g.cs + o] * (xc - x[o - g.sz]);
+  const bool inij = interior_ij(g, i, j);
+  const int ks = pz * zchunk, ke = (ks + zchunk < g.nz) ? ks + zchunk : g.nz;
+  long o = m + (long)ks * g.sz;
+  float xkm = (D == 3 && ks > 0 && ks < ke) ? x[o - g.sz] : 0.f;      // x[k-1] stays in a register while marching
+  const float lxc = CL ? wl::wl_cl_coef(i + 1, g.nx, cl.c[0]) : 0.f, lyc = CL ? wl::wl_cl_coef(j + 1, g.ny, cl.c[1]) : 0.f;
+  for (int k = ks; k < ke; k++, o += g.sz) {
+    const float xc = x[o];
+    pout[o] = xc / dt;
+    bool in = inij;
+    if (D == 3) in = in && k >= g.k0 && k < g.k1;
+    if (in) {
+      const float lx = CL ? lxc : L[o], ly = CL ? lyc : L[g.cs + o];
+      u[o] -= lx * (xc - x[o - 1]);
+      u[g.cs + o] -= ly * (xc - x[o - g.sy]);
+      if (D == 3) { const float lz = CL ? wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]) : L[2 * g.cs + o]; u[2 * g.cs + o] -= lz * (xc - xkm); }
+    }
+    xkm = xc;
+  }
 }
 // exact test of the constant-coefficient pattern over EVERY cell of L (ghosts included): L[I,a] == (I_a ∈ {1,2,N_a} ? 0 : c_a)
 template <int D>
@@ -461,13 +480,15 @@ int residual_part(float* r, const float* x, const float* z, const float* L, cons
   do { if ((D) == 3) { if (CLF) hipLaunchKernelGGL((KERN<3, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERN<3, 0>), __VA_ARGS__); } \
        else { if (CLF) hipLaunchKernelGGL((KERN<2, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERN<2, 0>), __VA_ARGS__); } } while (0)
 int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* Dg, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s) {
-  dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.nz));
-  DSEL2(g.D, cl.on, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa, cl);
+  const int zc = wl_march_chunk(g, g.nz);
+  dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
+  DSEL2(g.D, cl.on, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa, cl, zc);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s) {
-  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl);
+  const int zc = wl_march_chunk(g, g.nz);
+  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc);
   WL_LAUNCH_CHECK(); return 0;
 }
 // host-synchronising (update! time only): reads one interior face value per component, then verifies the whole array on device
