@@ -309,7 +309,7 @@ def test_zmarching_conv_diff_is_bit_identical(w, oracle, dims, body):
         assert np.abs(res[1][k][1] - outo[k][1]).max() < 2e-5
 
 
-@pytest.mark.parametrize("dims", [(64, 32, 48), (32, 32, 32), (128, 64), (20, 36, 24)])
+@pytest.mark.parametrize("dims", [(64, 32, 48), (32, 32, 32), (128, 64), (20, 36, 24), (128, 64, 32), (192, 32, 16)])
 @pytest.mark.parametrize("fused", [1, 0])
 def test_constant_coefficient_levels_are_bit_identical(w, dims, fused):
     """NoBody: L, D, iD evaluated from the cell position (wl::ConstL, verified at update!) vs loaded from memory — whole

@@ -137,43 +137,85 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_A(GridX g, float* __restrict_
   const int Kbeg = t.ks - 2, Kend = t.ke + 1;
   // coarse columns under the pair and its x-neighbours (PRO)
   unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0, cj0 = 0, cjm = 0, cjp = 0;
-  if (PRO && t.indom && t.j >= 1 && t.j <= g.ny - 2) {
+  if (PRO == 1 && t.indom && t.j >= 1 && t.j <= g.ny - 2) {
     q0 = (unsigned)dwn(t.i0 > 0 ? t.i0 - 1 : 0, pa.cx); q1 = (unsigned)dwn(t.i0, pa.cx); q2 = (unsigned)dwn(t.i0 + 1, pa.cx);
     q3 = (unsigned)dwn(t.i0 + 2 <= g.nx - 1 ? t.i0 + 2 : g.nx - 1, pa.cx);
     cj0 = (unsigned)dwn(t.j, pa.cy) * (unsigned)pa.gc.sy; cjm = (unsigned)dwn(t.j - 1, pa.cy) * (unsigned)pa.gc.sy; cjp = (unsigned)dwn(t.j + 1, pa.cy) * (unsigned)pa.gc.sy;
   }
+  // PRO == 2: every direction is coarsened (the usual case).  The pair (i0,i0+1) and its x-neighbours lie over the two coarse
+  // columns qa, qa+1; of the rows j±1 (planes K±1) one lies over the cell's own coarse row (plane), the other over the
+  // next one — by the parity of j (K).  Six coarse values per step, kept in registers: Cc (own plane, own row), Co (own
+  // plane, other row), Cz (other plane, own row); when K advances either Cz or — after Cc and Cz trade places — Co is
+  // replaced by two values fetched one step ahead.  2 loads per step instead of 12.
+  const bool jodd = (t.j & 1) != 0;
+  unsigned rc = 0, ro = 0;                 // qa + coarse row offset (own / other row)
+  const int nzc = pa.gc.nz;
+  float2 Cc = {0.f, 0.f}, Co = Cc, Cz = Cc, n_c = Cc, n_x0 = Cc;
+  auto cpl = [&](int p) { return (unsigned)(p < 0 ? 0 : (p > nzc - 1 ? nzc - 1 : p)) * (unsigned)pa.gc.sz; };
+  if (PRO == 2) {
+    if (t.indom) {
+      const unsigned qa = (unsigned)(t.i0 >> 1), cr = (unsigned)((t.j + 1) >> 1);
+      rc = qa + cr * (unsigned)pa.gc.sy;
+      ro = qa + (jodd ? cr - 1u : cr + 1u) * (unsigned)pa.gc.sy;
+    }
+    const int m = (Kbeg + 1) >> 1, zo = (Kbeg & 1) ? m - 1 : m + 1;
+    Cc = make_float2(pa.xc[rc + cpl(m)], pa.xc[rc + cpl(m) + 1]);
+    Co = make_float2(pa.xc[ro + cpl(m)], pa.xc[ro + cpl(m) + 1]);
+    Cz = make_float2(pa.xc[rc + cpl(zo)], pa.xc[rc + cpl(zo) + 1]);
+  }
   auto fetch = [&](int K) {
     const bool pl0 = t.indom && K >= g.k0 && K < g.k1;        // r of ghost planes/cells is 0
-    n_r0 = pl0 ? ld2(r, t.oc + (unsigned)K * (unsigned)g.sz) : make_float2(0.f, 0.f);
+    const unsigned o = t.oc + (unsigned)K * (unsigned)g.sz;
+    n_r0 = pl0 ? ld2(r, o) : make_float2(0.f, 0.f);
+    if (PRO) n_x0 = ((t.st0 || t.st1) && K >= t.ks && K < t.ke) ? ld2(pa.x, o) : make_float2(0.f, 0.f);
+    if (PRO == 2) {   // coarse values that become current at step K: plane m(K-1)+1; own row if K is even, other row if odd
+      const unsigned a = ((K & 1) ? ro : rc) + cpl((K >> 1) + 1);
+      n_c = make_float2(pa.xc[a], pa.xc[a + 1]);
+    }
   };
   fetch(Kbeg);
+  n_c = Cz;    // (the state for Kbeg was loaded directly; make the first transition below a no-op)
   for (int K = Kbeg; K <= Kend; K++) {
     e3 = e2; e2 = e1; e1 = e0; r2 = r1; r1 = r0; r0 = n_r0;
+    const float2 x0 = n_x0;
+    if (PRO == 2 && K > Kbeg) {
+      if (K & 1) { const float2 tmp = Cc; Cc = Cz; Cz = tmp; Co = n_c; }
+      else Cz = n_c;
+    }
     const unsigned o0 = t.oc + (unsigned)K * (unsigned)g.sz;
     const bool plK = K >= g.k0 && K < g.k1;
     const float lz0 = cf(g.gk + K + 1, g.gnz, c2), lzp0 = cf(g.gk + K + 2, g.gnz, c2);          // z-faces below / above plane K
     const float lz1 = cf(g.gk + K, g.gnz, c2), lz2 = cf(g.gk + K - 1, g.gnz, c2);
     if (PRO && plK) {   // increment!(fine;ω) with ϵ = x_c[down(I)]          src/Poisson.jl:100-104, mult :70-76
-      const int Kg = g.gk + K;
-      const unsigned ck0 = (unsigned)(dwn(Kg, pa.cz) - pa.gc.gk) * (unsigned)pa.gc.sz, ckm = (unsigned)(dwn(Kg - 1, pa.cz) - pa.gc.gk) * (unsigned)pa.gc.sz,
-                     ckp = (unsigned)(dwn(Kg + 1, pa.cz) - pa.gc.gk) * (unsigned)pa.gc.sz;
-      const float* __restrict__ xc = pa.xc;
-      const float va = xc[q0 + cj0 + ck0], v0 = xc[q1 + cj0 + ck0], v1 = xc[q2 + cj0 + ck0], vb = xc[q3 + cj0 + ck0];
+      float va, v0, v1, vb, ym0, yp0, ym1, yp1, zm0, zp0, zm1, zp1;
+      if (PRO == 2) {
+        const bool kodd = (K & 1) != 0;
+        va = Cc.x; v0 = Cc.x; v1 = Cc.y; vb = Cc.y;
+        ym0 = jodd ? Co.x : Cc.x; yp0 = jodd ? Cc.x : Co.x; ym1 = jodd ? Co.y : Cc.y; yp1 = jodd ? Cc.y : Co.y;
+        zm0 = kodd ? Cz.x : Cc.x; zp0 = kodd ? Cc.x : Cz.x; zm1 = kodd ? Cz.y : Cc.y; zp1 = kodd ? Cc.y : Cz.y;
+      } else {
+        const int Kg = g.gk + K;
+        const unsigned ck0 = (unsigned)(dwn(Kg, pa.cz) - pa.gc.gk) * (unsigned)pa.gc.sz, ckm = (unsigned)(dwn(Kg - 1, pa.cz) - pa.gc.gk) * (unsigned)pa.gc.sz,
+                       ckp = (unsigned)(dwn(Kg + 1, pa.cz) - pa.gc.gk) * (unsigned)pa.gc.sz;
+        const float* __restrict__ xc = pa.xc;
+        va = xc[q0 + cj0 + ck0]; v0 = xc[q1 + cj0 + ck0]; v1 = xc[q2 + cj0 + ck0]; vb = xc[q3 + cj0 + ck0];
+        ym0 = xc[q1 + cjm + ck0]; yp0 = xc[q1 + cjp + ck0]; ym1 = xc[q2 + cjm + ck0]; yp1 = xc[q2 + cjp + ck0];
+        zm0 = xc[q1 + cj0 + ckm]; zp0 = xc[q1 + cj0 + ckp]; zm1 = xc[q2 + cj0 + ckm]; zp1 = xc[q2 + cj0 + ckp];
+      }
       const float zs = lz0 + lzp0;
       float s = v0 * (t.in0 ? k.dxy0 - zs : 0.f);
       s += (va * k.cxa + v1 * k.cxb);
-      s += (xc[q1 + cjm + ck0] * k.ky + xc[q1 + cjp + ck0] * k.kyp);
-      s += (xc[q1 + cj0 + ckm] * lz0 + xc[q1 + cj0 + ckp] * lzp0);
+      s += (ym0 * k.ky + yp0 * k.kyp);
+      s += (zm0 * lz0 + zp0 * lzp0);
       if (t.in0) r0.x = r0.x - pa.w * s;
       s = v1 * (t.in1 ? k.dxy1 - zs : 0.f);
       s += (v0 * k.cxb + vb * k.cxc);
-      s += (xc[q2 + cjm + ck0] * k.ky + xc[q2 + cjp + ck0] * k.kyp);
-      s += (xc[q2 + cj0 + ckm] * lz0 + xc[q2 + cj0 + ckp] * lzp0);
+      s += (ym1 * k.ky + yp1 * k.kyp);
+      s += (zm1 * lz0 + zp1 * lzp0);
       if (t.in1) r0.y = r0.y - pa.w * s;
       if ((t.st0 || t.st1) && K >= t.ks && K < t.ke) {
         st2(pa.rnew, o0, r0, t.st0, t.st1);
-        const float2 xo = ld2(pa.x, o0);
-        st2(pa.x, o0, make_float2(xo.x + pa.w * v0, xo.y + pa.w * v1), t.st0, t.st1);
+        st2(pa.x, o0, make_float2(x0.x + pa.w * v0, x0.y + pa.w * v1), t.st0, t.st1);
       }
     }
     if (K < Kend) fetch(K + 1);
@@ -299,6 +341,7 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_B(GridX g, float* __restrict_
 }
 
 int g_pair_on = 1;
+int g_pro_fast = 1;   // bit 1 of gsrb_pair_enable: register-window prolongation when every direction is coarsened
 int zchunk2(const GridX& g, int HX, int HY) {
   const int nt = ptile_count(g.nx, g.ny, HX, HY);
   const int np = g.k1 - g.k0;
@@ -310,7 +353,7 @@ int zchunk2(const GridX& g, int HX, int HY) {
 }  // namespace
 
 namespace wl {
-void gsrb_pair_enable(int on) { g_pair_on = on; }
+void gsrb_pair_enable(int on) { g_pair_on = on & 1; g_pro_fast = (on & 2) == 0; }
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl) {
   return g_pair_on && cl.on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.gnz >= 10 && g.nz == g.gnz && g.cs < (1L << 30);
 }
@@ -325,7 +368,9 @@ int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const fl
   const int zc = zchunk2(g, 2, 2);
   const int nt = ptile_count(g.nx, g.ny, 2, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs2 pa{xc, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
-  hipLaunchKernelGGL((k_gsrb2_A<1>), dim3((unsigned)(8 * per * nch)), dim3(PT_N), 0, s, g, emid, r, zc, pa, cl);
+  const bool fullc = pa.cx && pa.cy && pa.cz && gc.gk == 0 && gc.nz == gc.gnz && 2 * (gc.nx - 2) == g.nx - 2 && 2 * (gc.ny - 2) == g.ny - 2 && 2 * (gc.nz - 2) == g.nz - 2;
+  if (fullc && g_pro_fast) hipLaunchKernelGGL((k_gsrb2_A<2>), dim3((unsigned)(8 * per * nch)), dim3(PT_N), 0, s, g, emid, r, zc, pa, cl);
+  else hipLaunchKernelGGL((k_gsrb2_A<1>), dim3((unsigned)(8 * per * nch)), dim3(PT_N), 0, s, g, emid, r, zc, pa, cl);
   WL_LAUNCH_CHECK(); return 0;
 }
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
