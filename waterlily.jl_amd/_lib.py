@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwlhip.so")
+LIB_PATH = os.environ.get("WLHIP_LIB") or os.path.join(_HERE, "libwlhip.so")   # WLHIP_LIB: explicit library (kernel A/B experiments)
 
 
 class wl_grid(C.Structure):

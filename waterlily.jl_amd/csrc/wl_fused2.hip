@@ -345,7 +345,7 @@ int g_pro_fast = 1;   // bit 1 of gsrb_pair_enable: register-window prolongation
 int zchunk2(const GridX& g, int HX, int HY) {
   const int nt = ptile_count(g.nx, g.ny, HX, HY);
   const int np = g.k1 - g.k0;
-  static const int target = getenv("WL_PAIR_WGS") ? atoi(getenv("WL_PAIR_WGS")) : 1536;
+  static const int target = getenv("WL_PAIR_WGS") ? atoi(getenv("WL_PAIR_WGS")) : 3072;
   int chunks = target >= 0 ? (target + nt - 1) / nt : (-target) / nt; if (chunks < 1) chunks = 1;
   int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
   return zc;
