@@ -74,6 +74,7 @@ SIGNATURES = {
     "wl_mg_smooth": (i32, [P, i32, i32, f32, P]),
     "wl_mg_set_fused": (i32, [P, i32]),
     "wl_mg_level_is_const": (i32, [P, i32]),
+    "wl_mg_smoother_kind": (i32, [P, i32]),
     "wl_mg_solve": (i32, [P, f64, i32, C.POINTER(i32), C.POINTER(f64), C.POINTER(f32), P]),
     "wl_mg_history": (i32, [P, C.POINTER(C.c_int16), i32]),
     "wl_mg_last_log": (i32, [P, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), i32]),

@@ -385,6 +385,12 @@ float* wl_mg_level_field(const wl_mg* mg, int l, const char* name) {
   return nullptr;
 }
 int wl_mg_smooth(wl_mg* mg, int l, int it, float w, void* st) { WL_CHECK(l >= 0 && l < (int)mg->lv.size(), "level out of range"); return mg->smooth(l, it <= 0 ? 4 : it, w, wl_stream(st)); }
+int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 temporally blocked (one cell per thread), 2 blocked pair kernels (constant coefficients)
+  if (l < 0 || l >= (int)mg->lv.size()) return -1;
+  const wl_mg::Level& p = mg->lv[(size_t)l];
+  if (!(mg->use_fused && wl::gsrb_fused_ok(p.x_, mg->perdir, p.dist))) return 0;
+  return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
+}
 int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
 int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }

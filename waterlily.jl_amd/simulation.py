@@ -163,6 +163,11 @@ class FusedSimulation:
         mg = lib().wl_sim_pois(self._h)
         return [bool(lib().wl_mg_level_is_const(mg, l)) for l in range(self.nlevels())]
 
+    def smoother_kinds(self):
+        """per level: 0 one kernel per pass, 1 temporally blocked smoother, 2 blocked pair kernels (constant coefficients)"""
+        mg = lib().wl_sim_pois(self._h)
+        return [int(lib().wl_mg_smoother_kind(mg, l)) for l in range(self.nlevels())]
+
     def measure_sphere_(self, center, R, eps=1.0):
         """measure!(sim) for AutoBody(|x-c|-R): closed form on device + update!(pois)"""
         c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
