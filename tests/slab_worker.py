@@ -74,6 +74,12 @@ def main():
         nu = dims[0] / 1600.0
         sim = slab.SlabSimulation(comm, dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv")
         ref = w.FusedSimulation(dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv") if rank == 0 else None
+        mg = L.wl_sim_pois(sim._h)
+        kinds = [L.wl_mg_smoother_kind(mg, l) for l in range(L.wl_mg_nlevels(mg))]
+        if rank == 0:
+            print("smoother kinds per level (slab run):", kinds, flush=True)
+        if dims[0] >= 64 and dims[1] >= 32 and dims[2] // size >= 8:
+            assert kinds[0] == 2, kinds      # the blocked pair kernels run on the distributed finest level
         for s in range(steps):
             sim.mom_step_()
             u = sim.gather_field("u", dist)

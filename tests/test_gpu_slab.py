@@ -6,7 +6,7 @@ from test_slab_cpu import run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,dims", [(2, "32x32x128"), (4, "32x32x256"), (2, "32x32x256"), (2, "64x64x64")])
+@pytest.mark.parametrize("n,dims", [(2, "32x32x128"), (4, "32x32x256"), (2, "32x32x256"), (2, "64x64x64"), (4, "64x64x256"), (3, "128x32x96")])
 def test_slab_ranks_match_single_domain(n, dims):
     out = run_ranks(n, "gpu_sim", dims, "3", timeout=600)
     for r in range(n):

@@ -123,8 +123,17 @@ int wl_mg::update(hipStream_t s) {                                              
   // constant-coefficient detection (exact, on device): only the levels that run the specialised kernels are checked
   for (size_t l = 0; l < lv.size(); l++) {
     lv[l].cl.on = 0;
-    if (use_constl && !perdir && !lv[l].dist && (l == 0 || wl::gsrb_fused_ok(lv[l].x_, perdir, lv[l].dist)))
+    if (use_constl && !perdir && (l == 0 || wl::gsrb_fused_ok(lv[l].x_, perdir, lv[l].dist) || (lv[l].dist && wl::gsrb_pair_geom_ok(lv[l].x_)))) {
       WL_TRY(wl::check_const_L(lv[l].L, lv[l].x_, &lv[l].cl, (int*)(ws.res_f + 7), s));
+      if (lv[l].dist && comm && comm->size > 1) {   // every rank must take the same path (the slab kernels differ in their halo exchanges)
+        const float bad = lv[l].cl.on ? 0.f : 1.f; float any = 1.f;
+        WL_HIP(hipMemcpyAsync(ws.res_f + 7, &bad, sizeof(float), hipMemcpyHostToDevice, s));
+        WL_TRY(wl::combine_results(comm, ws, s));                                          // res_f: max over ranks
+        WL_HIP(hipMemcpyAsync(&any, ws.res_f + 7, sizeof(float), hipMemcpyDeviceToHost, s));
+        WL_HIP(hipStreamSynchronize(s));
+        if (any != 0.f) lv[l].cl.on = 0;
+      }
+    }
   }
   return 0;
 }
@@ -145,7 +154,7 @@ int wl_mg::flush_pending(int l, float w, hipStream_t s) {
 int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* norms_done) {
   Level& p = lv[(size_t)l];
   if (norms_done) *norms_done = false;
-  const bool fused = it == 4 && use_fused && wl::gsrb_fused_ok(p.x_, perdir, p.dist);
+  const bool fused = it == 4 && use_fused && (wl::gsrb_fused_ok(p.x_, perdir, p.dist) || pair_slab(p));
   if (p.pend && !fused) WL_TRY(flush_pending(l, w, s));
   ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
   if (fused) {   // two z-marching kernels instead of six passes (+ the pending prolongation as an extra stage of kernel A)
@@ -153,10 +162,16 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     if (p.pend) {
       Level& coarse = lv[(size_t)l + 1];
       p.pend = false;
+      // z-slab: the tile pipeline recomputes the neighbour's planes it needs, so the exchanges are r (2 planes) before A and
+      // ϵ_mid (3 planes) + r' (2 planes) before B — instead of one exchange per colour sweep
+      WL_TRY(halo(p, p.r, 1, s, 2));
       { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s)); }
+      WL_TRY(halo(p, p.em, 1, s, 3)); WL_TRY(halo(p, p.rs, 1, s, 2));
       { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
     } else {
+      WL_TRY(halo(p, p.r, 1, s, 2));
       { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.x_, p.cl, s)); }
+      WL_TRY(halo(p, p.em, 1, s, 3));
       { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
       std::swap(p.r, p.rs);
     }
@@ -202,11 +217,11 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
     WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
     if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s, true));                         // its last step may be deferred into the smooth! below
     WL_TRY(smooth(l + 1, 4, w, s));
-    WL_TRY(halo(coarse, coarse.x, 1, s));                                                  // prolongation reads the coarse cells under my halo planes
+    WL_TRY(halo(coarse, coarse.x, 1, s, pair_slab(fine) ? 2 : 1));                         // prolongation reads the coarse cells under my halo planes
   }
   // prolongate!(fine.ϵ,coarse.x); increment!(fine;ω): the caller's next operation is smooth!(fine;ω) with the same ω — when that
   // smooth! runs as the temporally blocked kernel pair it absorbs this step as an extra pipeline stage (defer).
-  if (defer && use_fused && wl::gsrb_fused_ok(fine.x_, perdir, fine.dist)) { fine.pend = true; return 0; }
+  if (defer && use_fused && (wl::gsrb_fused_ok(fine.x_, perdir, fine.dist) || pair_slab(fine))) { fine.pend = true; return 0; }
   fine.pend = true;
   return flush_pending(l, w, s);
 }
@@ -388,6 +403,7 @@ int wl_mg_smooth(wl_mg* mg, int l, int it, float w, void* st) { WL_CHECK(l >= 0 
 int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 temporally blocked (one cell per thread), 2 blocked pair kernels (constant coefficients)
   if (l < 0 || l >= (int)mg->lv.size()) return -1;
   const wl_mg::Level& p = mg->lv[(size_t)l];
+  if (mg->pair_slab(p)) return 2;
   if (!(mg->use_fused && wl::gsrb_fused_ok(p.x_, mg->perdir, p.dist))) return 0;
   return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
 }

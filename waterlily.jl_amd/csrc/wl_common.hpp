@@ -233,6 +233,7 @@ int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStr
 // pair variant of the blocked smoother for constant-coefficient levels (wl_fused2.hip); chosen inside gsrb_fused_* when eligible
 void gsrb_pair_enable(int on);
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl);
+bool gsrb_pair_geom_ok(const GridX& g);
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s);
 int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s);
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,

@@ -295,6 +295,7 @@ static inline bool al8(const void* a, const void* b = nullptr, const void* c = n
 }
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s) {
   if (gsrb_pair_ok(g, cl) && al8(emid, r)) return gsrb_pair_A(emid, r, g, cl, s);
+  if (g.nz != g.gnz) { wl_set_error("blocked smoother on a z-slab level needs the pair kernels"); return WL_EINVAL; }
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{};
@@ -306,6 +307,7 @@ int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, co
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s) {
   if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s);
+  if (g.nz != g.gnz) { wl_set_error("blocked smoother on a z-slab level needs the pair kernels"); return WL_EINVAL; }
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs pa{xc, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
@@ -318,6 +320,7 @@ int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const f
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
                  const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {
   if (gsrb_pair_ok(g, cl) && al8(eps, rout, x, emid, r)) return gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s);
+  if (g.nz != g.gnz) { wl_set_error("blocked smoother on a z-slab level needs the pair kernels"); return WL_EINVAL; }
   const int zc = zchunk_for(g, 3);
   const int nt = ztile_count(g.nx, g.ny, 3), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   const unsigned nb = (unsigned)(8 * per * nch);

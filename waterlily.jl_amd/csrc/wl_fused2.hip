@@ -77,6 +77,9 @@ __device__ __forceinline__ void st2(float* __restrict__ p, unsigned o, float2 v,
   if (s0 && s1) *reinterpret_cast<float2*>(p + o) = v;
   else { if (s0) p[o] = v.x; if (s1) p[o + 1] = v.y; }
 }
+// plane K of the local array is an interior plane of the GLOBAL grid (single domain: k0 <= K < k1; on a z-slab also the
+// neighbour's planes held as ghost planes, which the tile pipeline recomputes instead of waiting for them)
+__device__ __forceinline__ bool pint(const GridX& g, int K) { const int Kg = g.gk + K; return K >= 0 && K < g.nz && Kg >= 1 && Kg <= g.gnz - 2; }
 // quirk Q4 (half_rangek, src/Poisson.jl:123-132): an odd last dimension leaves its last plane unswept
 __device__ __forceinline__ bool q4ok(const GridX& g, int Kg) { return !(Kg + 1 > 2 * (g.gnz / 2) - 1); }
 
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_A(GridX g, float* __restrict_
     Cz = make_float2(pa.xc[rc + cpl(zo)], pa.xc[rc + cpl(zo) + 1]);
   }
   auto fetch = [&](int K) {
-    const bool pl0 = t.indom && K >= g.k0 && K < g.k1;        // r of ghost planes/cells is 0
+    const bool pl0 = t.indom && pint(g, K);                     // r of ghost planes/cells is 0
     const unsigned o = t.oc + (unsigned)K * (unsigned)g.sz;
     n_r0 = pl0 ? ld2(r, o) : make_float2(0.f, 0.f);
     if (PRO) n_x0 = ((t.st0 || t.st1) && K >= t.ks && K < t.ke) ? ld2(pa.x, o) : make_float2(0.f, 0.f);
@@ -183,7 +186,7 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_A(GridX g, float* __restrict_
       else Cz = n_c;
     }
     const unsigned o0 = t.oc + (unsigned)K * (unsigned)g.sz;
-    const bool plK = K >= g.k0 && K < g.k1;
+    const bool plK = pint(g, K);
     const float lz0 = cf(g.gk + K + 1, g.gnz, c2), lzp0 = cf(g.gk + K + 2, g.gnz, c2);          // z-faces below / above plane K
     const float lz1 = cf(g.gk + K, g.gnz, c2), lz2 = cf(g.gk + K - 1, g.gnz, c2);
     if (PRO && plK) {   // increment!(fine;ω) with ϵ = x_c[down(I)]          src/Poisson.jl:100-104, mult :70-76
@@ -231,13 +234,13 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_A(GridX g, float* __restrict_
     const int off_oth = act1 ? oth1 : oth0, off_y = act1 ? t.lq + PL_H : t.lq;
     const float lxo = act1 ? k.cxc : k.cxa;
     // ---- sweep 1 on plane K-1
-    if ((K - 1) >= g.k0 && (K - 1) < g.k1 && (K - 1) >= t.ks - 1 && q4ok(g, g.gk + K - 1)) {
+    if (pint(g, K - 1) && (K - 1) >= t.ks - 1 && q4ok(g, g.gk + K - 1)) {
       const bool edge = (lz1 == 0.f) || (lz0 == 0.f);
       const float2 d = make_float2(edge ? k.ide0 : k.idm0, edge ? k.ide1 : k.idm1);
       pair_sweep(sA[pb], off_oth, off_y, act1, gate, lxo, k, lz1, lz0, r1, d, e2, e0, e1);
     }
     // ---- sweep 2 on plane K-2
-    if ((K - 2) >= g.k0 && (K - 2) < g.k1 && (K - 2) >= t.ks && q4ok(g, g.gk + K - 2)) {
+    if (pint(g, K - 2) && (K - 2) >= t.ks && q4ok(g, g.gk + K - 2)) {
       const bool edge = (lz2 == 0.f) || (lz1 == 0.f);
       const float2 d = make_float2(edge ? k.ide0 : k.idm0, edge ? k.ide1 : k.idm1);
       pair_sweep(sB[pb], off_oth, off_y, act1, gate, lxo, k, lz2, lz1, r2, d, e3, e1, e2);
@@ -271,7 +274,7 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_B(GridX g, float* __restrict_
   auto fetch = [&](int K) {
     const unsigned o0 = t.oc + (unsigned)K * (unsigned)g.sz;
     n_e0 = (t.indom && K >= 0 && K <= g.nz - 1) ? ld2(emid, o0) : make_float2(0.f, 0.f);
-    n_r1 = (t.indom && (K - 1) >= g.k0 && (K - 1) < g.k1) ? ld2(r, o0 - (unsigned)g.sz) : make_float2(0.f, 0.f);
+    n_r1 = (t.indom && pint(g, K - 1)) ? ld2(r, o0 - (unsigned)g.sz) : make_float2(0.f, 0.f);
     n_x3 = (stp && (K - 3) >= t.ks && (K - 3) < t.ke) ? ld2(x, o0 - 3u * (unsigned)g.sz) : make_float2(0.f, 0.f);
   };
   fetch(Kbeg);
@@ -288,13 +291,13 @@ __global__ void __launch_bounds__(PT_N, 8) k_gsrb2_B(GridX g, float* __restrict_
     const int off_oth = act1 ? oth1 : oth0, off_y = act1 ? t.lq + PL_H : t.lq;
     const float lxo = act1 ? k.cxc : k.cxa;
     // ---- sweep 3 on plane K-1
-    if ((K - 1) >= g.k0 && (K - 1) < g.k1 && (K - 1) >= t.ks - 2 && q4ok(g, g.gk + K - 1)) {
+    if (pint(g, K - 1) && (K - 1) >= t.ks - 2 && q4ok(g, g.gk + K - 1)) {
       const bool edge = (lz1 == 0.f) || (lz0 == 0.f);
       const float2 d = make_float2(edge ? k.ide0 : k.idm0, edge ? k.ide1 : k.idm1);
       pair_sweep(sA[pb], off_oth, off_y, act1, gate, lxo, k, lz1, lz0, r1, d, e2, e0, e1);
     }
     // ---- sweep 4 on plane K-2
-    if ((K - 2) >= g.k0 && (K - 2) < g.k1 && (K - 2) >= t.ks - 1 && q4ok(g, g.gk + K - 2)) {
+    if (pint(g, K - 2) && (K - 2) >= t.ks - 1 && q4ok(g, g.gk + K - 2)) {
       const bool edge = (lz2 == 0.f) || (lz1 == 0.f);
       const float2 d = make_float2(edge ? k.ide0 : k.idm0, edge ? k.ide1 : k.idm1);
       pair_sweep(sB[pb], off_oth, off_y, act1, gate, lxo, k, lz2, lz1, r2, d, e3, e1, e2);
@@ -354,9 +357,11 @@ int zchunk2(const GridX& g, int HX, int HY) {
 
 namespace wl {
 void gsrb_pair_enable(int on) { g_pair_on = on & 1; g_pro_fast = (on & 2) == 0; }
-bool gsrb_pair_ok(const GridX& g, const ConstL& cl) {
-  return g_pair_on && cl.on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.gnz >= 10 && g.nz == g.gnz && g.cs < (1L << 30);
+// geometry: even nx (float2), tiles not mostly empty, 32-bit offsets; a z-slab needs 3 ghost planes per side (kernel B's halo)
+bool gsrb_pair_geom_ok(const GridX& g) {
+  return g_pair_on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.gnz >= 10 && (g.k1 - g.k0) >= 8 && (g.nz == g.gnz || g.k0 >= 3) && g.cs < (1L << 30);
 }
+bool gsrb_pair_ok(const GridX& g, const ConstL& cl) { return cl.on && gsrb_pair_geom_ok(g); }
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s) {
   const int zc = zchunk2(g, 2, 2);
   const int nt = ptile_count(g.nx, g.ny, 2, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
@@ -368,7 +373,7 @@ int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const fl
   const int zc = zchunk2(g, 2, 2);
   const int nt = ptile_count(g.nx, g.ny, 2, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
   ProArgs2 pa{xc, x, rnew, gc, gc.nx < g.nx, gc.ny < g.ny, gc.gnz < g.gnz, w};
-  const bool fullc = pa.cx && pa.cy && pa.cz && gc.gk == 0 && gc.nz == gc.gnz && 2 * (gc.nx - 2) == g.nx - 2 && 2 * (gc.ny - 2) == g.ny - 2 && 2 * (gc.nz - 2) == g.nz - 2;
+  const bool fullc = pa.cx && pa.cy && pa.cz && gc.gk == 0 && gc.nz == gc.gnz && g.gk == 0 && g.nz == g.gnz && 2 * (gc.nx - 2) == g.nx - 2 && 2 * (gc.ny - 2) == g.ny - 2 && 2 * (gc.nz - 2) == g.nz - 2;
   if (fullc && g_pro_fast) hipLaunchKernelGGL((k_gsrb2_A<2>), dim3((unsigned)(8 * per * nch)), dim3(PT_N), 0, s, g, emid, r, zc, pa, cl);
   else hipLaunchKernelGGL((k_gsrb2_A<1>), dim3((unsigned)(8 * per * nch)), dim3(PT_N), 0, s, g, emid, r, zc, pa, cl);
   WL_LAUNCH_CHECK(); return 0;

@@ -166,6 +166,7 @@ __global__ void k_check_const_L(GridX g, const float* __restrict__ L, float c0, 
   // slab ranks: planes outside the global array (beyond the physical ghost plane) hold nothing meaningful
   const int Kj = (D == 3) ? g.gk + k + 1 : 1;
   if (D == 3 && (Kj < 1 || Kj > g.gnz)) return;
+  if (D == 3 && g.nz != g.gnz && (k < g.k0 - 1 || k > g.k1)) return;        // deeper ghost planes of a slab are never exchanged for L
   const long o = m + (long)k * g.sz;
   const float c[3] = {c0, c1, c2};
   const int I[3] = {i + 1, j + 1, Kj};

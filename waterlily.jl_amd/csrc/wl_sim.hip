@@ -327,7 +327,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   if (slab) {
     if (desc->exitBC) { delete s; wl_set_error("exitBC on z-slabs is not supported this round"); return WL_EINVAL; }
     if (desc->u || desc->u0 || desc->f || desc->p || desc->sigma || desc->V || desc->mu0 || desc->mu1) { delete s; wl_set_error("slab simulations own their arrays"); return WL_EINVAL; }
-    const int rc = wl_grid_slab(&s->g, desc->D, ng, comm->rank, comm->size, 2);
+    const int rc = wl_grid_slab(&s->g, desc->D, ng, comm->rank, comm->size, 3);   // 3 ghost planes: QUICK needs 2, kernel B of the blocked smoother 3
     if (rc != 0) { delete s; return rc; }
   } else s->g = wl_grid_single(desc->D, ng);
   s->G = gx(s->g);
