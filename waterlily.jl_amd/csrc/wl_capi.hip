@@ -198,7 +198,8 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
   // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
   {
     ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
-    if (!perdir && !fine.dist) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
+    if (!perdir && (!fine.dist || fine.cl.on)) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
+      WL_TRY(halo(fine, fine.r, 1, s));              // (slab: ϵ=r·iD of the neighbour's boundary plane is recomputed from its r; iD is evaluated from the position)
       WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s));
       std::swap(fine.r, fine.eps);
     } else {

@@ -244,7 +244,7 @@ struct wl_sim {
   }
   int project(float w, hipStream_t s) {                                                  // mom_project! :223-232
     const float dtl = w * dt.back();
-    if (ps && use_fuse_p && !d.perdir_mask && !comm) {
+    if (ps && use_fuse_p && !d.perdir_mask) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
       { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(sigma, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s)); }
