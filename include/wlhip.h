@@ -100,6 +100,12 @@ int wl_jacobi(float* eps, float* r, float* x, const float* L, const float* D, co
 int wl_gsrb(float* eps, float* r, float* x, const float* L, const float* D, const float* iD, const wl_grid* g, int it, float omega,
             unsigned perdir_mask, void* stream);                                        /* GaussSeidelRB! :141-148 */
 int wl_norms(const float* r, const wl_grid* g, double* host_l1, float* host_linf, void* scratch, void* stream); /* L₁, L∞ :190-191 */
+/* single-level solver.  z doubles as pcg!'s work array, exactly as p.z does in the reference. */
+int wl_pcg(float* eps, float* r, float* x, float* z, const float* L, const float* D, const float* iD, const wl_grid* g, int it,
+           unsigned perdir_mask, void* stream);                                         /* pcg!(p;it=6) :166-186 */
+int wl_poisson_solve(float* eps, float* r, float* x, float* z, const float* L, const float* D, const float* iD, const wl_grid* g,
+                     double tol, int itmx, unsigned perdir_mask, int* host_n, double* host_r1, float* host_rinf,
+                     void* stream);                                                     /* solver!(p::Poisson;tol,itmx) :212-223 */
 size_t wl_reduce_workspace_bytes(void);
 
 /* ---- multigrid transfer: src/MultiLevelPoisson.jl ---------------------------------------------- */

@@ -406,3 +406,67 @@ def test_pair_vcycle_with_fused_prolongation_is_bit_identical(w, oracle, N):
         for k, name in enumerate(("r", "x")):
             assert np.array_equal(res["pair"][l][k], po.field(name, l)), ("pair vs oracle", l, name)
             assert np.array_equal(res["pair"][l][k], res["passes"][l][k]), ("pair vs passes", l, name)
+
+
+# ---------------------------------------------------------------- single-level Poisson (pcg!, solver!)
+def poisson_setup_single_gpu(w, oracle, N):
+    """Poisson_setup(Poisson,N)   test/test_poisson.jl:1-12 on the HIP path"""
+    import ctypes as C
+    D = len(N)
+    cg = w.to_device(F(N + (D,), 1.0))
+    w.BC_(cg, (0,) * D)
+    xg, zg = w.jl_zeros(N), w.jl_zeros(N)
+    pois = w.Poisson(xg, cg, zg)
+    soln = np.asfortranarray(np.broadcast_to((np.arange(N[0], dtype=np.float32) + 1).reshape((N[0],) + (1,) * (D - 1)), N).copy(order="F"))
+    I = (1,) * D
+    soln -= soln[I]
+    w.mult_(pois, w.to_device(soln))          # z = mult!(pois, soln)
+    n = w.poisson.solver_(pois)
+    x = w.to_host(xg)
+    x -= x[I]
+    return oracle.L2(x - soln) / oracle.L2(soln), pois, n
+
+
+# test/test_poisson.jl:14-27 on the HIP path
+def test_single_level_poisson_solver(w, oracle):
+    err, pois, _ = poisson_setup_single_gpu(w, oracle, (5, 5))
+    Dexp = np.array([[0, 0, 0, 0, 0], [0, -2, -3, -2, 0], [0, -3, -4, -3, 0], [0, -2, -3, -2, 0], [0, 0, 0, 0, 0]], dtype=np.float32)
+    assert np.array_equal(w.to_host(pois.D), Dexp)
+    assert err < 1e-5
+    err, pois, n = poisson_setup_single_gpu(w, oracle, (2**6 + 2, 2**6 + 2))
+    assert err < 5e-6
+    assert n < 340 and pois.n[-1] == n
+    assert w.Linf(pois) < 2e-3
+    err, pois, n = poisson_setup_single_gpu(w, oracle, (2**4 + 2,) * 3)
+    assert err < 1e-6
+    assert n < 40
+
+
+@pytest.mark.parametrize("N", [(34, 18), (18, 18, 18), (20, 11, 14)])
+def test_pcg_matches_oracle(w, oracle, N):
+    """pcg!(p;it=6) from the same state: x, r, ϵ against the oracle.  The element-wise stages are the reference's statements;
+    α, β come from dot products whose summation order differs ⇒ tolerance 2e-5 relative to the field scale; and the whole
+    solver! needs the same number of pcg! calls as the oracle."""
+    rng = np.random.default_rng(61)
+    D = len(N)
+    L = np.asfortranarray(rng.uniform(0.3, 1.0, size=N + (D,)).astype(np.float32))
+    oracle.BC(L, (0,) * D)
+    x0 = np.asfortranarray(rng.uniform(-1, 1, size=N).astype(np.float32))
+    z0 = F(N)
+    inner = (slice(1, -1),) * D
+    z0[inner] = rng.uniform(-1, 1, size=tuple(n - 2 for n in N)).astype(np.float32)
+    z0[inner] -= z0[inner].mean(dtype=np.float64).astype(np.float32)
+    po = oracle.Poisson(x0.copy(order="F"), L.copy(order="F"), z0.copy(order="F"))
+    pg = w.Poisson(w.to_device(x0), w.to_device(L), w.to_device(z0))
+    po.residual(); w.residual_(pg)
+    po.pcg(0, 6); w.pcg_(pg, 6)
+    for name, a, b in (("x", w.to_host(pg.x), po.field("x")), ("r", w.to_host(pg.r), po.field("r")), ("eps", w.to_host(pg.eps), po.field("eps"))):
+        scale = max(1.0, float(np.abs(b).max()))
+        assert np.abs(a - b).max() <= 2e-5 * scale, (name, np.abs(a - b).max())
+    # full solver! from a fresh start
+    po = oracle.Poisson(x0.copy(order="F"), L.copy(order="F"), z0.copy(order="F"))
+    pg = w.Poisson(w.to_device(x0), w.to_device(L), w.to_device(z0))
+    no = po.solve()
+    ng = w.poisson.solver_(pg)
+    assert abs(ng - no) <= 1 and w.Linf(pg) < 2e-3
+    assert np.abs(w.to_host(pg.x) - po.field("x")).max() < 5e-3 * max(1.0, float(np.abs(po.field("x")).max()))

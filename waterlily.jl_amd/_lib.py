@@ -59,6 +59,8 @@ SIGNATURES = {
     "wl_jacobi": (i32, [P, P, P, P, P, P, G, i32, f32, u32, P]),
     "wl_gsrb": (i32, [P, P, P, P, P, P, G, i32, f32, u32, P]),
     "wl_norms": (i32, [P, G, C.POINTER(f64), C.POINTER(f32), P, P]),
+    "wl_pcg": (i32, [P, P, P, P, P, P, P, G, i32, u32, P]),
+    "wl_poisson_solve": (i32, [P, P, P, P, P, P, P, G, f64, i32, u32, P, P, P, P]),
     "wl_reduce_workspace_bytes": (sz, []),
     "wl_restrict": (i32, [P, G, P, G, P]),
     "wl_prolongate": (i32, [P, G, P, G, P]),

@@ -367,6 +367,62 @@ int wl_gsrb(float* eps, float* r, float* x, const float* L, const float* D, cons
   WL_TRY(wl::bc_per_scalar(eps, G, per, s));
   return wl::increment(r, x, eps, L, D, G, w, s);
 }
+// pcg!(p;it)   src/Poisson.jl:166-186.  The scalars ρ, α, β steer early exits exactly as in the reference, so each is read
+// back (two host reads per iteration, like the reference's blocking `⋅`).  Single domain only.
+static int pcg_impl(float* eps, float* r, float* x, float* z, const float* L, const float* D, const float* iD, const GridX& G, int it, unsigned per, const RedWs& ws, hipStream_t s) {
+  const float tiny = 10 * 1.1920929e-07f;                                                  // 10eps(T)
+  double h;
+  WL_TRY(wl::pcg_stage(0, eps, r, x, z, L, D, iD, G, 0.f, 0, ws, s));                       // z = ϵ = r·iD ; rho = r⋅z
+  WL_TRY(wl::read_results(ws, &h, 1, nullptr, 0, s));
+  float rho = (float)h;
+  if (std::fabs(rho) < tiny) return 0;
+  for (int i = 1; i <= it; i++) {
+    WL_TRY(wl::bc_per_scalar(eps, G, per, s));                                             // perBC!(ϵ)
+    WL_TRY(wl::pcg_stage(1, eps, r, x, z, L, D, iD, G, 0.f, 0, ws, s));                     // z = Aϵ ; perdot(z,ϵ)
+    WL_TRY(wl::read_results(ws, &h, 1, nullptr, 0, s));
+    const float alpha = rho / (float)h;
+    if (std::fabs(alpha) < 1e-2f || std::fabs(alpha) > 1e2f) return 0;                      // alpha should be O(1)
+    const int more = i < it;
+    WL_TRY(wl::pcg_stage(2, eps, r, x, z, L, D, iD, G, alpha, more, ws, s));                // x += αϵ ; r -= αz [; z = r·iD ; rho2 = r⋅z]
+    if (!more) return 0;
+    WL_TRY(wl::read_results(ws, &h, 1, nullptr, 0, s));
+    const float rho2 = (float)h;
+    if (std::fabs(rho2) < tiny) return 0;
+    const float beta = rho2 / rho;
+    WL_TRY(wl::pcg_stage(3, eps, r, x, z, L, D, iD, G, beta, 0, ws, s));                    // ϵ = βϵ + z
+    rho = rho2;
+  }
+  return 0;
+}
+int wl_pcg(float* eps, float* r, float* x, float* z, const float* L, const float* D, const float* iD, const wl_grid* g, int it, unsigned per, void* st) {
+  GRID_ARG(g); WL_CHECK(g->D == 2 || g->nz == g->gnz, "pcg! is single-domain"); DEFAULT_WS();
+  return pcg_impl(eps, r, x, z, L, D, iD, G, it <= 0 ? 6 : it, per, ws, wl_stream(st));
+}
+// solver!(p::Poisson;tol,itmx)   src/Poisson.jl:212-223
+int wl_poisson_solve(float* eps, float* r, float* x, float* z, const float* L, const float* D, const float* iD, const wl_grid* g, double tol, int itmx, unsigned per,
+                     int* host_n, double* host_r1, float* host_rinf, void* st) {
+  GRID_ARG(g); WL_CHECK(g->D == 2 || g->nz == g->gnz, "solver!(::Poisson) is single-domain"); DEFAULT_WS();
+  hipStream_t s = wl_stream(st);
+  const double r1tol = (tol / 10.0) * (double)wl_ninside_global(*g);
+  WL_TRY(wl::bc_per_scalar(x, G, per, s));                                                 // residual!: perBC!(x) :93
+  WL_TRY(wl::residual(r, x, z, L, D, iD, G, ws, s));
+  double r1 = 0.0; float rinf = 0.f;
+  int np = 0;
+  const int cap = itmx <= 0 ? 1000 : itmx;
+  while (np < cap) {
+    WL_TRY(pcg_impl(eps, r, x, z, L, D, iD, G, 6, per, ws, s));
+    WL_TRY(wl::norms_dev(r, G, ws, 1, 0, s));
+    double hd[2]; float hf[1];
+    WL_TRY(wl::read_results(ws, hd, 2, hf, 1, s));
+    r1 = (double)(float)hd[1]; rinf = hf[0]; np++;
+    if (r1 < r1tol && (double)rinf < tol) break;
+  }
+  WL_TRY(wl::bc_per_scalar(x, G, per, s));                                                 // :221
+  if (host_n) *host_n = np;
+  if (host_r1) *host_r1 = r1;
+  if (host_rinf) *host_rinf = rinf;
+  return 0;
+}
 int wl_norms(const float* r, const wl_grid* g, double* l1, float* linf, void* scratch, void* st) {
   GRID_ARG(g); WL_TRY(wl_ctx_ensure());
   const RedWs ws = wl_red_ws(scratch ? scratch : wl_ctx().red);

@@ -224,6 +224,7 @@ int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const 
 int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s);
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s);
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
+int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* L, const float* Dg, const float* iD, const GridX& g, float a, int more, const RedWs& ws, hipStream_t s);
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s);
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s);

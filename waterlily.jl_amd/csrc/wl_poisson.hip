@@ -178,6 +178,34 @@ __global__ void k_check_const_L(GridX g, const float* __restrict__ L, float c0, 
   }
   if (bad) atomicOr(flag, 1);
 }
+// ---- pcg!(p;it)   src/Poisson.jl:166-186 — Jacobi-preconditioned conjugate gradients of the single-level Poisson ----
+// stage 0: z = ϵ = r·iD                      (+ Σ r·z)          :168-169
+// stage 1: z = mult(I,L,D,ϵ)                 (+ Σ z·ϵ)          :173-174
+// stage 2: x += α·ϵ ; r -= α·z  [; z = r·iD  (+ Σ r·z)]         :176-180
+// stage 3: ϵ = β·ϵ + z                                          :183
+template <int D, int STAGE>
+__global__ void k_pcg(GridX g, float* __restrict__ eps, float* __restrict__ r, float* __restrict__ x, float* __restrict__ z, const float* __restrict__ L,
+                      const float* __restrict__ Dg, const float* __restrict__ iD, float a, int more, double* __restrict__ part) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  double acc = 0.0;
+  const int nsl = wl_nslots(g);
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) {
+      const long o = m + (long)k * g.sz;
+      if (STAGE == 0) { const float v = r[o] * iD[o]; z[o] = v; eps[o] = v; acc += (double)r[o] * (double)v; }
+      if (STAGE == 1) { const float v = Ax<D>(g, o, L, Dg, eps); z[o] = v; acc += (double)v * (double)eps[o]; }
+      if (STAGE == 2) {
+        x[o] += a * eps[o];
+        const float rn = r[o] - a * z[o];
+        r[o] = rn;
+        if (more) { const float v = rn * iD[o]; z[o] = v; acc += (double)rn * (double)v; }
+      }
+      if (STAGE == 3) eps[o] = a * eps[o] + z[o];
+    }
+  }
+  if (STAGE != 3) { acc = block_sum(acc); if (threadIdx.x == 0) part[blockIdx.x] = acc; }
+}
 // deterministic second stage: res_d[slot] = Σ partials
 __global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
   double a = 0.0;
@@ -561,6 +589,16 @@ int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, 
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s) {
   if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
   else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// one stage of pcg! ; stages 0-2 leave their dot product in ws.res_d[0]
+int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* L, const float* Dg, const float* iD, const GridX& g, float a, int more, const RedWs& ws, hipStream_t s) {
+  dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.k1 - g.k0));
+#define WL_PCG(ST) do { if (g.D == 3) hipLaunchKernelGGL((k_pcg<3, ST>), grid, dim3(WL_BLOCK), 0, s, g, eps, r, x, z, L, Dg, iD, a, more, ws.pa); \
+                        else hipLaunchKernelGGL((k_pcg<2, ST>), grid, dim3(WL_BLOCK), 0, s, g, eps, r, x, z, L, Dg, iD, a, more, ws.pa); } while (0)
+  switch (stage) { case 0: WL_PCG(0); break; case 1: WL_PCG(1); break; case 2: WL_PCG(2); break; default: WL_PCG(3); }
+#undef WL_PCG
+  if (stage != 3 && !(stage == 2 && !more)) hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {

@@ -13,7 +13,7 @@ module WaterLilyHIPExt
 
 using WaterLily
 import WaterLily: BC!, perBC!, exitBC!, conv_diff!, BDIM!, scale_u!, CFL, L₂, mom_step!, mom_project!,
-                  set_diag!, update!, mult!, residual!, increment!, Jacobi!, GaussSeidelRB!, restrict!, prolongate!,
+                  set_diag!, update!, mult!, residual!, increment!, Jacobi!, GaussSeidelRB!, pcg!, restrict!, prolongate!,
                   restrictL!, solver!, Vcycle!, L₁, L∞, quick, vanLeer, cds, Flow, Poisson, MultiLevelPoisson, AbstractPoisson
 
 const libwlhip = get(ENV, "WLHIP_LIB", "libwlhip.so")
@@ -116,6 +116,14 @@ Jacobi!(p::HPois; it=1, ω=1) = chk(ccall((:wl_jacobi, libwlhip), Cint, (Ptr{Cfl
                                          p.ϵ.ptr, p.r.ptr, p.x.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), it, ω, pmask(p.perdir), C_NULL))
 GaussSeidelRB!(p::HPois; it=4, ω=1) = chk(ccall((:wl_gsrb, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cfloat, Cuint, Ptr{Cvoid}),
                                                 p.ϵ.ptr, p.r.ptr, p.x.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), it, ω, pmask(p.perdir), C_NULL))
+pcg!(p::HPois; it=6, kwargs...) = chk(ccall((:wl_pcg, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cuint, Ptr{Cvoid}),
+                                           p.ϵ.ptr, p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), it, pmask(p.perdir), C_NULL))   # src/Poisson.jl:166
+function solver!(p::HPois; tol=2e-3, itmx=1e3)                                                                                            # src/Poisson.jl:212
+    n = Ref{Cint}()
+    chk(ccall((:wl_poisson_solve, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cdouble, Cint, Cuint, Ref{Cint}, Ptr{Cdouble}, Ptr{Cfloat}, Ptr{Cvoid}),
+              p.ϵ.ptr, p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), tol, Int32(min(itmx, typemax(Int32))), pmask(p.perdir), n, C_NULL, C_NULL, C_NULL))
+    push!(p.n, n[])
+end
 function norms(p::HPois)
     l1 = Ref{Cdouble}(); li = Ref{Cfloat}()
     chk(ccall((:wl_norms, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}, Ptr{Cvoid}), p.r.ptr, sgrid(p.r), l1, li, C_NULL, C_NULL)); (Float32(l1[]), li[])

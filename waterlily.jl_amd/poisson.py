@@ -68,6 +68,20 @@ def GaussSeidelRB_(p, it=4, w=1.0):
 smooth_ = GaussSeidelRB_   # src/MultiLevelPoisson.jl:106
 
 
+def pcg_(p, it=6):
+    """pcg!(p;it)   src/Poisson.jl:166-186"""
+    check(lib().wl_pcg(ptr(p.eps), ptr(p.r), ptr(p.x), ptr(p.z), ptr(p.L), ptr(p.D), ptr(p.iD), C.byref(p.g), int(it), perdir_mask(p.perdir), stream()))
+
+
+def poisson_solver_(p, tol=2e-3, itmx=1e3):
+    """solver!(p::Poisson;tol,itmx)   src/Poisson.jl:212-223 — residual!, pcg! until L₁ < tol/10·N and L∞ < tol"""
+    n, r1, rinf = C.c_int(), C.c_double(), C.c_float()
+    check(lib().wl_poisson_solve(ptr(p.eps), ptr(p.r), ptr(p.x), ptr(p.z), ptr(p.L), ptr(p.D), ptr(p.iD), C.byref(p.g), float(tol), int(itmx),
+                                 perdir_mask(p.perdir), C.byref(n), C.byref(r1), C.byref(rinf), stream()))
+    p.n.append(n.value)
+    return n.value
+
+
 def norms(p):
     """(L₁(p), L∞(p))   :190-191 — one fused pass"""
     l1, linf = C.c_double(), C.c_float()
@@ -203,4 +217,5 @@ def update_ml_(ml):
 
 
 def solver_(b, **kw):
-    return b.solver_(**kw)
+    """solver!(b) — dispatches on the type like the reference (Poisson: pcg!, MultiLevelPoisson: V-cycles)"""
+    return poisson_solver_(b, **kw) if isinstance(b, Poisson) else b.solver_(**kw)
