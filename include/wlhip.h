@@ -158,10 +158,16 @@ int wl_sim_grid(const wl_sim* s, wl_grid* out);
 int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀ BC, (src/Flow.jl:141-145) after the caller filled u */
 /* implementation switches (tests compare the variants): "convz" (z-marching conv_diff!), "fused_smoother" — default 1 */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
+/* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
+   g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).
+   NULL U1 keeps the boundary velocity; NULL a0 and a1 switches the forcing off. */
+int wl_sim_set_forcing(wl_sim* s, const float* U1, const float* a0, const float* a1);
+int wl_accelerate(float* r, const wl_grid* g, const float a[3], void* stream);   /* accelerate! for a uniform acceleration: r[I,i] += a_i */
 int wl_sim_update(wl_sim* s, void* stream);             /* update!(pois) after μ₀ changed (measure!, src/WaterLily.jl:148) */
 int wl_sim_mom_step(wl_sim* s, void* stream);           /* mom_step!(flow,pois): appends Δt */
 int wl_sim_dt(const wl_sim* s, float* host_out, int cap);      /* flow.Δt (host vector, src/Flow.jl:127) */
 double wl_sim_time(const wl_sim* s);                    /* time(flow) = sum(Δt[1:end-1]) :174 */
+float wl_sim_dt_last(const wl_sim* s);                 /* Δt[end] */
 /* sub-phases for parity tests: 0 u⁰.=u;scale_u!(0) 1 mom_predict! 2 mom_project!(1) 3 mom_correct! 4 mom_project!(.5) 5 push!(Δt,CFL) */
 int wl_sim_phase(wl_sim* s, int phase, void* stream);
 /* analytic initial conditions evaluated on device (apply!(u0,u), src/Flow.jl:81-83): kind 0 = uBC tuple,

@@ -470,3 +470,47 @@ def test_pcg_matches_oracle(w, oracle, N):
     ng = w.poisson.solver_(pg)
     assert abs(ng - no) <= 1 and w.Linf(pg) < 2e-3
     assert np.abs(w.to_host(pg.x) - po.field("x")).max() < 5e-3 * max(1.0, float(np.abs(po.field("x")).max()))
+
+
+# ---------------------------------------------------------------- time-dependent uniform uBC / body force
+# test/test_flow.jl:111-121 on the HIP path (Float32 here; the reference test runs Float64)
+def test_increasing_body_force(w, oracle):
+    N, jerk = 8, 4
+    Us = math.sqrt(N)
+    sim = w.FusedSimulation((N, N), (Us, 0.0), N, nu=0.001, dt=0.001, perdir=(1,), g=lambda i, t: t * jerk if i == 1 else 0.0)
+    sim.sim_step_(1.0)
+    u = sim.field("u")
+    uFinal = np.float32(Us + 0.5 * jerk * sim.time() ** 2)
+    assert oracle.L2(u[:, :, 0] - uFinal) < 1e-4 and oracle.L2(u[:, :, 1]) < 1e-4
+
+
+def test_forced_steps_match_oracle(w, oracle):
+    """accelerate! + time-dependent boundary velocity: uBC(i,t) = (1+t/2, 0, 0), g(i,t) = (0, 0.3t, -0.1): ten steps against the oracle."""
+    dims = (24, 16, 16)
+    ufn = lambda i, t: 1.0 + 0.5 * t if i == 1 else 0.0
+    dufn = lambda i, t: 0.5 if i == 1 else 0.0
+    gfn = lambda i, t: (0.0, 0.3 * t, -0.1)[i - 1]
+    so = oracle.Simulation(dims, lambda i, x, t: ufn(i, t), 16, U=1, nu=0.01, T=np.float32, g=lambda i, x, t: gfn(i, t), duBC_dt=lambda i, x, t: dufn(i, t))
+    sg = w.FusedSimulation(dims, ufn, 16, U=1, nu=0.01, g=gfn, duBC_dt=dufn)
+    for step in range(10):
+        so.step(remeasure=False); sg.mom_step_()
+        assert sg.pois_n[-2:] == so.pois_n[-2:]
+        assert np.abs(sg.field("u") - so.u).max() < 3e-5 * np.abs(so.u).max(), step       # the flow accelerates to |u|≈3
+        assert abs(float(sg.dt[-1]) - float(so.dt[-1])) <= 1e-5 * float(so.dt[-1])
+
+
+# test/test_flow.jl:161-173 on the HIP path: circle in an accelerating flow uBC(i,x,t) = i==1 ? t : 0 — added mass
+def test_circle_in_accelerating_flow(w):
+    radius, H = 32, 16
+    n = radius * 2 * H
+    c = (H * radius, H * radius)
+    sim = w.FusedSimulation((n, n), lambda i, t: t if i == 1 else 0.0, radius, U=1, has_body=True, duBC_dt=lambda i, t: 1.0 if i == 1 else 0.0)
+    sim.measure_sphere_(c, radius, 1.0)
+    sim.mom_step_()
+    force = sim.pressure_force_sphere(c, radius) / (math.pi * radius**2)
+    assert np.allclose(force, [-1, 0], atol=0.04)            # added-mass force of a circle: -π R² dU/dt
+    u = sim.field("u")
+    assert u.max() / u[1, 1, 0] > 1.91                       # potential flow: maximum speed 2U at the shoulder
+    for _ in range(3):
+        sim.mom_step_()
+    assert all(k <= 2 for k in sim.pois_n)

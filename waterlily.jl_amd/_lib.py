@@ -88,9 +88,12 @@ SIGNATURES = {
     "wl_sim_init_flow": (i32, [P, P]),
     "wl_sim_set_option": (i32, [P, C.c_char_p, i32]),
     "wl_sim_update": (i32, [P, P]),
+    "wl_sim_set_forcing": (i32, [P, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]),
+    "wl_accelerate": (i32, [P, G, C.POINTER(f32), P]),
     "wl_sim_mom_step": (i32, [P, P]),
     "wl_sim_dt": (i32, [P, C.POINTER(f32), i32]),
     "wl_sim_time": (f64, [P]),
+    "wl_sim_dt_last": (f32, [P]),
     "wl_sim_phase": (i32, [P, i32, P]),
     "wl_sim_apply_ic": (i32, [P, i32, P]),
     "wl_sim_measure_sphere": (i32, [P, C.POINTER(f32), f32, f32, P]),

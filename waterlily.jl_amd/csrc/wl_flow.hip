@@ -274,6 +274,14 @@ __global__ void k_conv_q1(GridX g, float* __restrict__ Phi, const float* __restr
   }
 }
 
+// accelerate!(r,t,g,U) for accelerations that are uniform in space: r[I,i] += a_i on ALL cells   src/Flow.jl:69-73
+// (the host evaluates g(i,t)+dU(i,t)/dt; position-dependent g/uBC are not a device path)
+__global__ void k_accelerate(float* __restrict__ r, long cs, long n, float a0, float a1, float a2) {
+  for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (long)gridDim.x * WL_BLOCK) {
+    const int c = (int)(q / cs);
+    r[q] += (c == 0) ? a0 : (c == 1 ? a1 : a2);
+  }
+}
 // BDIM!  src/Flow.jl:176-180 (+ scale_u! :211-214 folded in through pre/post)
 // pass A: f = u⁰ + dt f − V on ALL cells
 __global__ void k_bdim_f(GridX g, float* __restrict__ f, const float* __restrict__ u0, const float* __restrict__ V, float dt, long n) {
@@ -621,6 +629,11 @@ int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, 
     hipLaunchKernelGGL(k_bdim_f, dim3(grid1d((size_t)n)), dim3(WL_BLOCK), 0, s, g, f, u0, V, dt, n);
     DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, scale_after);
   }
+  WL_LAUNCH_CHECK(); return 0;
+}
+int accelerate(float* r, const GridX& g, const float* a, hipStream_t s) {
+  const long n = g.cs * g.D;
+  hipLaunchKernelGGL(k_accelerate, dim3(grid1d((size_t)n)), dim3(WL_BLOCK), 0, s, r, g.cs, n, a[0], a[1], g.D == 3 ? a[2] : 0.f);
   WL_LAUNCH_CHECK(); return 0;
 }
 int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s) {

@@ -189,6 +189,8 @@ struct wl_sim {
   bool swap_ok = false;      // u and u⁰ are handle-owned and every ghost of u is rewritten by BC! (no exitBC)
   float* ps = nullptr;       // spare pressure array (out-of-place x·dt and x/dt around the solve; two swaps restore p's identity)
   bool use_fuse_p = true;
+  bool forcing = false;      // uniform g(i,t)+dU(i,t)/dt supplied by the host for the current step (accelerate!, src/Flow.jl:69-73)
+  float acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};   // at t₀ (predictor) and t₁ (corrector)
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
   ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
@@ -214,7 +216,7 @@ struct wl_sim {
   }
   int exit_bc(hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
-    if (us && !d.has_body) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
+    if (us && !d.has_body && !forcing) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
       ProfScope pc(WL_PROF_CONVDIFF, s);
       if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
         WL_TRY(wl::conv_diff_z(f, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
@@ -222,6 +224,7 @@ struct wl_sim {
       } else WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, mg->lv[0].cl, s));
     } else {
       { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
+      if (forcing) WL_TRY(wl::accelerate(f, G, acc0, s));                                  // accelerate!(f,t₀,g,uBC)
       WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
     }
     WL_TRY(bc_u(s));
@@ -229,7 +232,7 @@ struct wl_sim {
     return 0;
   }
   int correct(hipStream_t s) {                                                           // mom_correct! :205-210
-    if (us && !d.has_body) {   // the advecting field is u itself: write the new u to the spare array and swap
+    if (us && !d.has_body && !forcing) {   // the advecting field is u itself: write the new u to the spare array and swap
       { ProfScope pc(WL_PROF_CONVDIFF, s);
         if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
           WL_TRY(wl::conv_diff_z(f, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
@@ -239,6 +242,7 @@ struct wl_sim {
       return bc_u(s);
     }
     { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u, s)); }
+    if (forcing) WL_TRY(wl::accelerate(f, G, acc1, s));                                    // accelerate!(f,t₁,g,uBC)
     WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
@@ -399,8 +403,20 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
 int wl_sim_update(wl_sim* s, void* st) { return s->mg->update(wl_stream(st)); }
+int wl_sim_set_forcing(wl_sim* s, const float* U1, const float* a0, const float* a1) {
+  const int D = s->d.D;
+  if (U1) for (int c = 0; c < D; c++) s->d.uBC[c] = U1[c];
+  s->forcing = a0 != nullptr || a1 != nullptr;
+  for (int c = 0; c < 3; c++) { s->acc0[c] = (a0 && c < D) ? a0[c] : 0.f; s->acc1[c] = (a1 && c < D) ? a1[c] : 0.f; }
+  return 0;
+}
+int wl_accelerate(float* r, const wl_grid* g, const float* a, void* st) {
+  WL_CHECK(wl_grid_ok(g) && a, "bad argument"); WL_TRY(wl_ctx_ensure());
+  return wl::accelerate(r, gx(*g), a, wl_stream(st));
+}
 int wl_sim_mom_step(wl_sim* s, void* st) { return s->mom_step(wl_stream(st)); }
 int wl_sim_dt(const wl_sim* s, float* out, int cap) { const int n = (int)s->dt.size(); for (int k = 0; k < n && k < cap; k++) out[k] = s->dt[(size_t)k]; return n; }
+float wl_sim_dt_last(const wl_sim* s) { return s->dt.back(); }
 double wl_sim_time(const wl_sim* s) { float t = 0.f; for (size_t k = 0; k + 1 < s->dt.size(); k++) t += s->dt[k]; return (double)t; }
 int wl_sim_phase(wl_sim* s, int phase, void* st) {
   hipStream_t q = wl_stream(st);

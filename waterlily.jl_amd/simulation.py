@@ -48,9 +48,18 @@ class FusedSimulation:
     """The composite path: one `wl_sim` handle holds every field in HBM and runs mom_step! (src/Flow.jl:156-167)
     as a fixed sequence of fused HIP kernels on one stream.  This is what bench.py times."""
 
-    def __init__(self, dims, uBC, L, U=None, dt=0.25, nu=0.0, perdir=(), exitBC=False, lam=core.QUICK, has_body=False, ic="uBC", u0=None):
+    def __init__(self, dims, uBC, L, U=None, dt=0.25, nu=0.0, perdir=(), exitBC=False, lam=core.QUICK, has_body=False, ic="uBC", u0=None,
+                 g=None, duBC_dt=None):
+        """uBC: tuple, or a function uBC(i,t) that is uniform in space (i = 1..D as in the reference) together with its time
+        derivative duBC_dt(i,t) (the reference differentiates it with ForwardDiff, src/Flow.jl:72-73); g: body force g(i,t),
+        uniform in space.  Position-dependent uBC/g are not a device path."""
         core.device()
         D = len(dims)
+        self._ufn = uBC if callable(uBC) else None
+        self._dufn, self._gfn = duBC_dt, g
+        if self._ufn is not None:
+            assert U is not None, "`U` (velocity scale) must be specified if boundary conditions `uBC` is a `Function`"   # src/WaterLily.jl:99
+            uBC = tuple(float(self._ufn(i + 1, 0.0)) for i in range(D))
         if U is None:
             U = float(np.sqrt(sum(float(v) ** 2 for v in uBC)))
         self.U, self.L, self.D = float(U), float(L), D
@@ -102,7 +111,21 @@ class FusedSimulation:
         check(lib().wl_h2d(lib().wl_sim_field(self._h, name.encode()), a.ctypes.data_as(C.c_void_p), a.nbytes, stream()))
         check(lib().wl_stream_sync(stream()))
 
+    def _forcing(self):
+        """uBC(i,t₁) and g(i,t)+dU(i,t)/dt at t₀, t₁ for the coming step (mom_step!, src/Flow.jl:157; accelerate! :69-73)"""
+        if self._ufn is None and self._gfn is None:
+            return
+        D = self.D
+        dtl = np.float32(lib().wl_sim_dt_last(self._h))
+        t1 = np.float32(np.float32(lib().wl_sim_time(self._h)) + dtl)      # t₁ = sum(Δt) ; t₀ = t₁ - Δt[end]   src/Flow.jl:157
+        t0 = np.float32(t1 - dtl)
+        arr = lambda v: (C.c_float * 3)(*([float(x) for x in v] + [0.0] * (3 - D)))
+        U1 = arr([self._ufn(i + 1, float(t1)) for i in range(D)]) if self._ufn is not None else None
+        acc = lambda t: arr([(self._gfn(i + 1, float(t)) if self._gfn else 0.0) + (self._dufn(i + 1, float(t)) if (self._ufn and self._dufn) else 0.0) for i in range(D)])
+        check(lib().wl_sim_set_forcing(self._h, U1, acc(t0), acc(t1)))
+
     def mom_step_(self):
+        self._forcing()
         check(lib().wl_sim_mom_step(self._h, stream()))
 
     def phase_(self, k):
