@@ -21,15 +21,16 @@ def w():
 
 def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
     sims = {}
-    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0}), ("zmarch", {"convz": 1})):
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0}), ("zmarch", {"convz": 1}), ("convm", {"convm": 1})):
         s = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
         for k, v in opts.items():
             s.set_option(k, v)
         for _ in range(2):
             s.mom_step_()
         sims[tag] = (s.field("u"), s.field("p"), s.pois_n, s.dt)
+        s.set_option("convm", 0)      # (process-wide switch)
         del s
-    for tag in ("plain", "zmarch"):
+    for tag in ("plain", "zmarch", "convm"):
         assert sims[tag][2] == sims["fast"][2] and sims[tag][3] == sims["fast"][3]
         assert np.array_equal(sims[tag][0], sims["fast"][0]), tag
         assert np.array_equal(sims[tag][1], sims["fast"][1]), tag

@@ -1,6 +1,6 @@
-for v in default tx32 tx64 default tx32 tx64; do
+for v in default w6 w7 default w6 w7; do
 if [ $v != default ]; then export WLHIP_LIB=$PWD/tools/var/libwlhip_$v.so; else unset WLHIP_LIB; fi
-python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_$v.log 2>&1
+WL_OPT_convm=0 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/ab_$v.log 2>&1
 python - <<PY
 import json
 j=json.loads(open("gpurun_out/ab_$v.log").read().strip().splitlines()[-1])

@@ -4,6 +4,7 @@
 #include <cstdlib>
 
 #include "wl_common.hpp"
+#include "wl_conv_cell.hpp"
 
 namespace {
 
@@ -64,160 +65,22 @@ __global__ void k_fin_max(const float* __restrict__ pmax, int n, float* __restri
   mx = block_max(mx); if (threadIdx.x == 0) *om = mx;
 }
 
-// ---- convective schemes   src/Flow.jl:4-6,27-36 --------------------------------------------------
-// median(a,b,c) src/Flow.jl:27-36 — one v_med3_f32; identical value to the reference's branchy form for non-NaN inputs
-// (the branchy form compiled to ~700 exec-mask instructions per cell in conv_diff!).
-__device__ __forceinline__ float median3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
-// x/6 correctly rounded without the ~10-instruction IEEE division sequence: float(double(x)·(1/6)) equals x/6 for EVERY
-// float x (verified exhaustively over all 2^24 significands × normal/subnormal exponents, tools/check_div6.py): the
-// quotient of a float by 6 is never closer than ~2^-27 (relative) to a rounding midpoint, far above the 2^-53 product error.
-#ifdef WL_NO_DIV6
-__device__ __forceinline__ float div6(float x) { return x / 6; }
-#else
-__device__ __forceinline__ float div6(float x) { return (float)((double)x * (1.0 / 6.0)); }
-#endif
-template <int SCH> __device__ __forceinline__ float lam(float u, float c, float d) {
-  if (SCH == WL_QUICK) return median3(div6(5 * c + 2 * d - u), c, median3(10 * c - 9 * u, c, d));
-  if (SCH == WL_VANLEER) return (c <= fminf(u, d) || c >= fmaxf(u, d)) ? c : c + (d - c) * (c - u) / (d - u);
-  return (c + d) / 2;
-}
-
-// flux Φ_ab at the lower b-face of the cell at offset o (component a advected, direction b).
-//  pb   : Julia index of that cell along b (2..Ng_b),  nb = Ng_b,  sb = stride along b, sa = stride along a
-//  variant by position: pb==2 lower boundary (ϕuL / periodic ϕuP), 3..nb-1 inner (ϕu), pb==nb upper (ϕuR / periodic reuse of index 2)
-//  returns the value V such that the reference does  r[I] += V  for the cell on the UPPER side of the face
-//  (lower/inner: V=Φ) — for the upper-boundary face the caller applies r[I-δ] += (-ϕuR + ν∂) itself.
-template <int SCH>
-__device__ __forceinline__ float flux_inner(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu) {
-  const float U = (ub[o] + ub[o - sa]) / 2;                                              // ϕ(i,CI(I,j),u)   src/Flow.jl:3,47
-  const float conv = U > 0 ? U * lam<SCH>(f[o - 2 * sb], f[o - sb], f[o]) : U * lam<SCH>(f[o + sb], f[o], f[o - sb]);   // ϕu :8
-  return conv - nu * (f[o] - f[o - sb]);
-}
-template <int SCH>
-__device__ __forceinline__ float flux_lowerL(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu) {
-  const float U = (ub[o] + ub[o - sa]) / 2;
-  const float conv = U > 0 ? U * ((f[o] + f[o - sb]) / 2) : U * lam<SCH>(f[o + sb], f[o], f[o - sb]);                   // ϕuL :10
-  return conv - nu * (f[o] - f[o - sb]);
-}
-template <int SCH>
-__device__ __forceinline__ float flux_lowerP(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu, long op) {
-  const float U = (ub[o] + ub[o - sa]) / 2;
-  const float conv = U > 0 ? U * lam<SCH>(f[op], f[o - sb], f[o]) : U * lam<SCH>(f[o + sb], f[o], f[o - sb]);           // ϕuP :9
-  return conv - nu * (f[o] - f[o - sb]);
-}
-template <int SCH>
-__device__ __forceinline__ float flux_upperR(const float* __restrict__ f, const float* __restrict__ ub, long o, long sb, long sa, float nu) {
-  const float U = (ub[o] + ub[o - sa]) / 2;
-  const float conv = U < 0 ? U * ((f[o] + f[o - sb]) / 2) : U * lam<SCH>(f[o - 2 * sb], f[o - sb], f[o]);               // ϕuR :11
-  return -conv + nu * (f[o] - f[o - sb]);                                                 // upperBoundary! :57
-}
-
-// conv_diff!(r,u,Φ,λ;ν,perdir) in gather form   src/Flow.jl:38-62, ranges src/core.jl:55-57,188-190
-// One thread per cell of the WHOLE array (r .= 0 included).  For cell I (Julia indices) and component a:
-//   r[I,a] = Σ_b [ +Φ_ab(I) − Φ_ab(I+δ_b) ]  taken in the reference's (j inner) order, direction b
-//   contributing iff I_b ∈ 2..Ng_b−1 and every other I_c ∈ 2..Ng_c (upper ghost INCLUDED, as inside_u does).
-// Straight-line, fully unrolled and predicated: every load of the (a,b) pair is independent of the others (the
-// first version kept the a/b loops rolled — 32 VGPRs, one long chain of dependent loads, 6.4 ms at 512³).
-// One flux formula serves all face variants:
-//   Φ = U·X − ν(f[P]−f[P−δ]),  X = λ(upwind triple by sign of U), overridden by the plain average ϕ where the
-//   reference uses ϕuL (lower wall, U>0) / ϕuR (upper wall, U<0); periodic lower faces only change the address
-//   of the far-upwind point (ϕuP).  r[I−δ] += −ϕuR+ν∂ equals r[I−δ] −= (ϕuR−ν∂) bit for bit, so the upper wall
-//   needs no separate accumulation form.  Addresses that a masked lane would take out of range are clamped to
-//   its own cell (values unused).
-template <int SCH>
-__device__ __forceinline__ float face_flux(float U, float t0, float t1, float t2, float avg, bool use_avg, float fc, float fm, float nu) {
-  float X = lam<SCH>(t0, t1, t2);
-  X = use_avg ? avg : X;
-  return U * X - nu * (fc - fm);
-}
-// PER = 0: no periodic direction (no wrapped addresses, no branches at all); IDX = int when every component offset fits 31 bits
-// FUSE = 1 appends BDIM! for the NoBody case (μ₁≡0, V≡0; src/Flow.jl:176-180 + the folded scale_u!):
-//   f = u⁰ + Δt·r (all cells) ; u_out = (u·pre + μ₀·f)·post (interior).  u_out must not alias the advecting field u.
-struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre, post; int scale_after; int cl_on; float cl_c[3]; };
-// XSH = 1 (non-periodic only): the flux through a cell's +x face is its x-neighbour's lower-face flux, fetched from lane+1
-// by a wave shuffle instead of being recomputed (3 of the 18 fluxes per cell).  Waves then overlap by one lane: 63 cells
-// per wave, the last lane only feeds lane 62.
-template <int D, int SCH, int PER, typename IDX, int FUSE, int XSH>
+template <int D, int SCH, int PER, typename IDX, int FUSE>
 #ifndef WL_CD_WAVES
 #define WL_CD_WAVES 1
 #endif
 __global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, float* __restrict__ r, const float* __restrict__ u, float nu, unsigned per, int kfirst, BdimArgs bd) {
   int i, j; long m; int pz;
-  bool valid, store;
-  if (XSH) {
-    const unsigned h = blockIdx.x, q8 = h & 7u, sq = h >> 3;
-    const long nbx = (g.sz + 251) / 252;                       // 4 waves × 63 cells per block
-    const unsigned per8 = (unsigned)((nbx + 7) >> 3);
-    pz = (int)(sq / per8);
-    const long bx = (long)q8 * per8 + (sq - (unsigned)pz * per8);
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    m = (bx * 4 + wv) * 63 + lane;
-    valid = m < g.sz;
-    store = valid && lane < 63;
-    if (!valid) m = g.sz - 1;                                  // keep every lane alive for the shuffle; nothing is stored
-    j = (int)(m / g.nx); i = (int)(m - (long)j * g.nx);
-  } else {
-    wl_tile(g, m, pz);
-    if (!cell_ij(g, m, i, j)) return;
-    valid = store = true;
-  }
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j)) return;
+  const bool store = true;
   const int k = (D == 3) ? kfirst + pz : 0;
   const IDX o = (IDX)(m + (long)k * g.sz);
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2};    // Julia (global) indices
   const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
   const IDX st[3] = {1, (IDX)g.sy, (IDX)g.sz};
-  bool ok = true;
-#pragma unroll
-  for (int c = 0; c < D; c++) ok = ok && (I[c] >= 2);
   float out[3];
-#pragma unroll
-  for (int a = 0; a < D; a++) {
-    const float* __restrict__ f = u + (long)a * g.cs;
-    const IDX sa = ok ? st[a] : 0;
-    float acc = 0.f;
-    const float f0 = f[o];
-#pragma unroll
-    for (int b = 0; b < D; b++) {
-      const float* __restrict__ ub = u + (long)b * g.cs;
-      const bool pb = PER && ((per >> b) & 1u);
-      const bool con = ok && (I[b] <= N[b] - 1);
-      const bool lowb = (I[b] == 2), upb = (I[b] + 1 == N[b]);
-      if (XSH && b == 0) {   // x faces: own lower-face flux for every cell whose face exists (upper ghost included), upper from lane+1
-        const bool topb = (I[0] == N[0]);
-        const IDX s1 = ok ? 1 : 0;
-        const float fm1 = f[o - s1], fm2 = f[o - (lowb ? s1 : 2 * s1)], fp1 = f[o + ((ok && !topb) ? 1 : 0)];
-        const float Ul = (ub[o] + ub[o - sa]) / 2;
-        const bool posl = Ul > 0;
-        const float Pl = face_flux<SCH>(Ul, posl ? fm2 : fp1, posl ? fm1 : f0, posl ? f0 : fm1, (f0 + fm1) / 2, (lowb && posl) || (topb && (Ul < 0)), f0, fm1, nu);
-        const float Pu = __shfl_down(Pl, 1, 64);
-        acc = con ? acc + Pl : acc;
-        acc = con ? acc - Pu : acc;
-        continue;
-      }
-      const IDX sb = con ? st[b] : 0;
-      // star of f along b, clamped where the variant never reads it
-      const IDX om2 = lowb ? (pb ? (IDX)(N[b] - 4) * sb : -sb) : -2 * sb;       // far upwind of my lower face (ϕuP wraps)
-      const IDX op2 = (I[b] + 2 <= N[b]) ? 2 * sb : sb;                          // far downwind of my upper face
-      const float fm2 = f[o + om2], fm1 = f[o - sb], fp1 = f[o + sb], fp2 = f[o + op2];
-      // lower face of I: U = ϕ(a, CI(I,b), u) = (u_b[I] + u_b[I−δ_a])/2        src/Flow.jl:3,47
-      const float Ul = (ub[o] + ub[o - sa]) / 2;
-      const bool posl = Ul > 0;
-      const float Pl = face_flux<SCH>(Ul, posl ? fm2 : fp1, posl ? fm1 : f0, posl ? f0 : fm1, (f0 + fm1) / 2, lowb && !pb && posl, f0, fm1, nu);
-      // upper face of I = lower face of I+δ_b
-      float Pu;
-      if (PER && upb && pb) {   // periodic: Φ[CIj(j,I,2)] — the wrapped lower-face flux at index 2   src/Flow.jl:62 (rare plane)
-        const long o2 = (long)o + (long)(2 - I[b]) * sb;
-        Pu = flux_lowerP<SCH>(f, ub, o2, sb, sa, nu, o2 + (long)(N[b] - 4) * sb);
-      } else {
-        const float Uu = (ub[o + sb] + ub[o + sb - sa]) / 2;
-        const bool posu = Uu > 0;
-        Pu = face_flux<SCH>(Uu, posu ? fm1 : fp2, posu ? f0 : fp1, posu ? fp1 : f0, (fp1 + f0) / 2, upb && !pb && (Uu < 0), fp1, f0, nu);
-      }
-      acc = con ? acc + Pl : acc;
-      acc = con ? acc - Pu : acc;
-    }
-    out[a] = acc;
-  }
+  cd_cell<D, SCH, PER, IDX, 0, 0>(g, u, o, I, N, st, nu, per, nullptr, out);
   if (FUSE) {
     bool in = interior_ij(g, i, j);
     if (D == 3) in = in && k >= g.k0 && k < g.k1;
@@ -566,18 +429,16 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
-  static int xsh_env = -1;
-  if (xsh_env < 0) { const char* e = getenv("WL_CONV_XSH"); xsh_env = e ? atoi(e) : 0; }   // measured SLOWER at 512³ (7.0 vs 6.3 ms/step): opt-in only
-  const bool xsh = (per == 0) && xsh_env;   // +x face fluxes by wave shuffle: 63 cells per wave
-  const long nbx = xsh ? (g.sz + 251) / 252 : 0;
-  const dim3 grid = xsh ? dim3((unsigned)(8L * ((nbx + 7) >> 3) * (klast - kfirst))) : wl_plane_grid(g, klast - kfirst);
+  const dim3 grid = wl_plane_grid(g, klast - kfirst);
   const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
   BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0, 0, {0.f, 0.f, 0.f}};
   const BdimArgs ba = bd ? *bd : b0;
+  const bool march = D == 3 && wl::conv_march_ok(g);   // z-marching variant (wl_convm.hip): same arithmetic, the z-star in registers
+  if (march) WL_TRY(wl::conv_march(r, u, g, nu, per, SCH, kfirst, klast, bd, s));
 #define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \
-  do { if (xsh) hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF, 1 - PERF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba); \
-       else hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF, 0>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba); } while (0)
-  if (bd) { if (per) { if (small) WL_CD(1, int, 1); else WL_CD(1, long, 1); } else { if (small) WL_CD(0, int, 1); else WL_CD(0, long, 1); } }
+  hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba)
+  if (march) {}
+  else if (bd) { if (per) { if (small) WL_CD(1, int, 1); else WL_CD(1, long, 1); } else { if (small) WL_CD(0, int, 1); else WL_CD(0, long, 1); } }
   else    { if (per) { if (small) WL_CD(1, int, 0); else WL_CD(1, long, 0); } else { if (small) WL_CD(0, int, 0); else WL_CD(0, long, 0); } }
 #undef WL_CD
   if (Phi) {
