@@ -219,6 +219,7 @@ int residual_part(float* r, const float* x, const float* z, const float* L, cons
 int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s);
 int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s);
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s);
+int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s);
 // computes L₁/L∞ of r into ws.res_d[slot_d], ws.res_f[slot_f] (device) — ghosts of r are zero by construction
 int norms_dev(const float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 int increment(float* r, float* x, const float* eps, const float* L, const float* D, const GridX& g, float w, hipStream_t s);

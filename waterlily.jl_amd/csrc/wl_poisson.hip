@@ -156,6 +156,64 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
     xkm = xc;
   }
 }
+// The corrector's mom_project! tail with CFL's flux_out folded in (src/Flow.jl:227-230 + :234-244): out-of-place u (u_out ≠ u_in, so
+// the +δ neighbours' projected values can be recomputed from u_in — the same statements their owners execute, hence the same
+// bits), σ = flux_out of the projected field, per-workgroup max over the planes [kfirst,klast) of σ (ghost cells: stale Φ, Q1).
+// Valid when BC! does not change what flux_out reads: wall-normal boundary faces already hold U and L is 0 there
+// (non-periodic, no exitBC).  Cells outside the interior of u_out are left for BC! to write.
+template <int D, int CL>
+__global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout,
+                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  float mx = -INFINITY;
+  if (cell_ij(g, m, i, j)) {
+    const bool inij = interior_ij(g, i, j);
+    const int ks = pz * zchunk, ke = (ks + zchunk < g.nz) ? ks + zchunk : g.nz;
+    long o = m + (long)ks * g.sz;
+    float xkm = (D == 3 && ks > 0 && ks < ke) ? x[o - g.sz] : 0.f, xc = (ks < ke) ? x[o] : 0.f;
+    float lx = 0.f, lxp = 0.f, ly = 0.f, lyp = 0.f;
+    if (CL) {
+      lx = wl::wl_cl_coef(i + 1, g.nx, cl.c[0]); lxp = wl::wl_cl_coef(i + 2, g.nx, cl.c[0]);
+      ly = wl::wl_cl_coef(j + 1, g.ny, cl.c[1]); lyp = wl::wl_cl_coef(j + 2, g.ny, cl.c[1]);
+    }
+    for (int k = ks; k < ke; k++, o += g.sz) {
+      const float xkp = (D == 3 && k + 1 < g.nz) ? x[o + g.sz] : 0.f;
+      pout[o] = xc / dt;
+      bool in = inij;
+      if (D == 3) in = in && k >= g.k0 && k < g.k1;
+      float sg;
+      if (in) {
+        float lz = 0.f, lzp = 0.f;
+        if (CL) { if (D == 3) { lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]); lzp = wl::wl_cl_coef(g.gk + k + 2, g.gnz, cl.c[2]); } }
+        else {
+          lx = L[o]; lxp = L[o + 1]; ly = L[g.cs + o]; lyp = L[g.cs + o + g.sy];
+          if (D == 3) { lz = L[2 * g.cs + o]; lzp = L[2 * g.cs + o + g.sz]; }
+        }
+        const float uxn = uin[o] - lx * (xc - x[o - 1]), uxp = uin[o + 1] - lxp * (x[o + 1] - xc);
+        const float uyn = uin[g.cs + o] - ly * (xc - x[o - g.sy]), uyp = uin[g.cs + o + g.sy] - lyp * (x[o + g.sy] - xc);
+        uout[o] = uxn; uout[g.cs + o] = uyn;
+        sg = 0.f;
+        sg += (fmaxf(0.f, uxp) + fmaxf(0.f, -uxn));
+        sg += (fmaxf(0.f, uyp) + fmaxf(0.f, -uyn));
+        if (D == 3) {
+          const float uzn = uin[2 * g.cs + o] - lz * (xc - xkm), uzp = uin[2 * g.cs + o + g.sz] - lzp * (xkp - xc);
+          uout[2 * g.cs + o] = uzn;
+          sg += (fmaxf(0.f, uzp) + fmaxf(0.f, -uzn));
+        }
+        sigma[o] = sg;
+      } else sg = sigma[o];
+      if (k >= kfirst && k < klast) mx = fmaxf(mx, sg);
+      xkm = xc; xc = xkp;
+    }
+  }
+  mx = block_max(mx);
+  if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
+}
+__global__ void k_fin_max2(const float* __restrict__ pmax, int n, float* __restrict__ om) {
+  float mx = -INFINITY; for (int q = threadIdx.x; q < n; q += WL_BLOCK) mx = fmaxf(mx, pmax[q]);
+  mx = block_max(mx); if (threadIdx.x == 0) *om = mx;
+}
 // exact test of the constant-coefficient pattern over EVERY cell of L (ghosts included): L[I,a] == (I_a ∈ {1,2,N_a} ? 0 : c_a)
 template <int D>
 __global__ void k_check_const_L(GridX g, const float* __restrict__ L, float c0, float c1, float c2, int* __restrict__ flag) {
@@ -518,6 +576,17 @@ int div_residual(float* z, float* xout, float* r, const float* x, const float* u
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s) {
   const int zc = wl_march_chunk(g, g.nz);
   DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// projection tail + CFL's σ and max(σ) -> ws.res_f[slot_f]; u_out must not alias u_in
+int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s) {
+  if (uout == uin) { wl_set_error("project_cfl: output aliases input"); return WL_EINVAL; }
+  int kfirst = 0, klast = 1;
+  if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  const int zc = wl_march_chunk(g, g.nz);
+  const dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
+  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm);
+  hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 // host-synchronising (update! time only): reads one interior face value per component, then verifies the whole array on device

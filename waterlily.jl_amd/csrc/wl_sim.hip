@@ -246,8 +246,11 @@ struct wl_sim {
     WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
-  int project(float w, hipStream_t s) {                                                  // mom_project! :223-232
+  bool use_fuse_cfl = true;  // the corrector's projection tail also produces CFL's σ and max(σ)
+  bool cfl_done = false;
+  int project(float w, hipStream_t s, bool with_cfl = false) {                           // mom_project! :223-232
     const float dtl = w * dt.back();
+    cfl_done = false;
     if (ps && use_fuse_p && !d.perdir_mask) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
@@ -255,7 +258,10 @@ struct wl_sim {
       std::swap(p, ps); l0.x = p;
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
-      WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
+      if (with_cfl && use_fuse_cfl && us && !d.exitBC) {   // + flux_out and its maximum; projected u lands in the spare array
+        WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s));
+        std::swap(u, us); cfl_done = true;
+      } else WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
       std::swap(p, ps); l0.x = p;
       return bc_u(s);
     }
@@ -266,7 +272,8 @@ struct wl_sim {
     return bc_u(s);
   }
   int cfl(hipStream_t s) {                                                               // CFL :234-237
-    WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s));
+    if (!cfl_done) WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s));
+    cfl_done = false;
     WL_TRY(wl::combine_results(comm, mg->ws, s));                                        // max over ranks
     float mx; WL_TRY(wl::read_results(mg->ws, nullptr, 0, &mx, 1, s));
     dt.push_back(std::fmin(10.f, 1.0f / (mx + 5 * d.nu)));
@@ -281,7 +288,7 @@ struct wl_sim {
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s));
     WL_TRY(correct(s));
-    WL_TRY(project(0.5f, s));
+    WL_TRY(project(0.5f, s, true));
     return cfl(s);
   }
 };
@@ -398,6 +405,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
+  if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
