@@ -5,7 +5,20 @@
 
 #include <cstring>
 
-wl_comm::~wl_comm() { if (gather) (void)hipFree(gather); }
+wl_comm::~wl_comm() {
+  if (gather) (void)hipFree(gather);
+  if (cs) { (void)hipStreamSynchronize(cs); (void)hipStreamDestroy(cs); }
+  if (ev_ready) (void)hipEventDestroy(ev_ready);
+  if (ev_done) (void)hipEventDestroy(ev_done);
+}
+int wl_comm::ensure_async() {
+  if (!cs) {
+    WL_HIP(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    WL_HIP(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+    WL_HIP(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
+  }
+  return 0;
+}
 int wl_comm::ensure_scratch() {
   if (!gather) WL_HIP(hipMalloc(&gather, (size_t)size * 128));
   return 0;
@@ -104,6 +117,20 @@ int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t
     if (rc != 0) { (void)c->group_end(); return rc; }
   }
   return c->group_end();
+}
+int halo_async_begin(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t compute) {
+  if (!c || c->size == 1 || g.D != 3 || g.nz == g.gnz) return 0;
+  WL_TRY(c->ensure_async());
+  WL_HIP(hipEventRecord(c->ev_ready, compute));
+  WL_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
+  WL_TRY(halo(c, a, g, ncomp, depth, c->cs));
+  WL_HIP(hipEventRecord(c->ev_done, c->cs));
+  return 0;
+}
+int halo_async_wait(wl_comm* c, hipStream_t compute) {
+  if (!c || c->size == 1 || !c->cs) return 0;
+  WL_HIP(hipStreamWaitEvent(compute, c->ev_done, 0));
+  return 0;
 }
 int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s) {
   if (!c || c->size == 1) return 0;

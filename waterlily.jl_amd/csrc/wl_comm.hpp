@@ -12,11 +12,18 @@ struct wl_comm {
   virtual int group_begin() { return 0; }
   virtual int group_end() { return 0; }
   int ensure_scratch();
+  // second HIP stream for halo exchanges that overlap interior stencil work (+ the two events that order it with the compute stream)
+  hipStream_t cs = nullptr; hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+  int ensure_async();
 };
 
 namespace wl {
 // exchange `depth` planes of an ncomp-component field along z with both neighbours
 int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s);
+// the same exchange on the communicator's own stream: it starts when everything queued on `compute` so far is done (begin) and
+// `compute` waits for it only where the caller says so (wait) — kernels launched in between overlap with the transfer
+int halo_async_begin(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t compute);
+int halo_async_wait(wl_comm* c, hipStream_t compute);
 // ws.res_d[0..7] <- Σ over ranks, ws.res_f[0..7] <- max over ranks (on device, stream ordered); no-op without comm
 int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s);
 // in-place all-gather of the owned planes [k0,k1) of a replicated (full) array whose rank blocks are contiguous

@@ -195,7 +195,7 @@ int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per,
 int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                   float dt, float pre, float post, const ConstL& cl, hipStream_t s);
+                   float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka = -(1 << 30), int kb = 1 << 30, bool q1 = true);   // [ka,kb): plane sub-range; q1: also the Φ ghost pass
 int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 bool conv_z_ok(const GridX& g, unsigned per);
 int conv_diff_z(float* f, const float* u_adv, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, int scheme, float dt, float pre, float post, hipStream_t s);

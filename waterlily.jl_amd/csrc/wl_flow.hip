@@ -425,10 +425,22 @@ int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s) {
 }
 
 template <int D, int SCH>
-static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s, const BdimArgs* bd) {
-  // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes)
+static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s, const BdimArgs* bd, int ka, int kb, bool q1) {
+  // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes), cut to [ka,kb)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  if (D == 3) { if (ka > kfirst) kfirst = ka; if (kb < klast) klast = kb; }
+  if (!q1) Phi = nullptr;
+  if (kfirst >= klast) {
+    if (Phi) {
+      long cmax = (long)g.ny * (D == 3 ? g.nz : 1);
+      cmax = cmax > (long)g.nx * (D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (D == 3 ? g.nz : 1);
+      cmax = cmax > g.sz ? cmax : g.sz;
+      hipLaunchKernelGGL((k_conv_q1<D, SCH>), dim3((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)D, 1), dim3(WL_BLOCK), 0, s, g, Phi, u, nu, per);
+      WL_LAUNCH_CHECK();
+    }
+    return 0;
+  }
   const dim3 grid = wl_plane_grid(g, klast - kfirst);
   const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
   BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0, 0, {0.f, 0.f, 0.f}};
@@ -450,11 +462,12 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   WL_LAUNCH_CHECK(); return 0;
 }
 template <int D>
-static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s, const BdimArgs* bd) {
+static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s, const BdimArgs* bd,
+                            int ka = -(1 << 30), int kb = 1 << 30, bool q1 = true) {
   switch (scheme) {
-    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s, bd);
-    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s, bd);
-    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s, bd);
+    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1);
+    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1);
+    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1);
   }
   wl_set_error("unknown scheme"); return WL_EINVAL;
 }
@@ -476,10 +489,10 @@ int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, 
 }
 // conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: f and u_out written, u_out must not alias u_adv
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                   float dt, float pre, float post, const ConstL& cl, hipStream_t s) {
+                   float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka, int kb, bool q1) {
   if (u_out == u_adv) { wl_set_error("conv_diff_bdim: output aliases the advecting field"); return WL_EINVAL; }
   BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, cl.on, {cl.c[0], cl.c[1], cl.c[2]}};
-  return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
+  return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd, ka, kb, q1) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
 }
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s) {
   const int scale_after = (post != 1.f) ? 1 : 0;

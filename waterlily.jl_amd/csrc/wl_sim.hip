@@ -193,12 +193,35 @@ struct wl_sim {
   float acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};   // at t₀ (predictor) and t₁ (corrector)
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
-  ~wl_sim() { delete mg; if (own) (void)hipFree(own); }
+  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); }
 
   // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
-  int bc_u(hipStream_t s) { WL_TRY(wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s)); return wl::halo(comm, u, G, d.D, 2, s); }
+  // On slabs the exchange runs on the communicator's own stream; the compute stream waits for it (sync_u) only where the halo
+  // planes are first read, so the interior planes of the next conv_diff! overlap with the transfer.
+  bool use_overlap = true;
+  bool u_pending = false;    // an exchange of the array that is now `u` or `u0` is in flight
+  int sync_u(hipStream_t s) { if (u_pending) { u_pending = false; return wl::halo_async_wait(comm, s); } return 0; }
+  int bc_u(hipStream_t s) {
+    WL_TRY(sync_u(s));
+    WL_TRY(wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s));
+    if (comm && use_overlap) { WL_TRY(wl::halo_async_begin(comm, u, G, d.D, 2, s)); u_pending = true; return 0; }
+    return wl::halo(comm, u, G, d.D, 2, s);
+  }
+  // fused conv_diff!+BDIM! (NoBody): interior planes first when the advecting field's halo is still in flight
+  int conv_fused(const float* uadv, float* uout, float pre, float post, hipStream_t s) {
+    const wl::ConstL& cl = mg->lv[0].cl;
+    if (u_pending && G.D == 3 && G.k1 - G.k0 > 4) {
+      WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k0 + 2, G.k1 - 2, false));
+      WL_TRY(sync_u(s));
+      WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), G.k0 + 2, false));
+      return wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k1 - 2, 1 << 30, true);
+    }
+    WL_TRY(sync_u(s));
+    return wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s);
+  }
   bool use_convz = false;    // z-marching conv_diff! (each flux once): bit-identical but measured 6 % SLOWER than the gather kernel at 512³ (opt-in)
   int conv_only(const float* uadv, hipStream_t s) {     // conv_diff!(f,uadv,σ) without BDIM!
+    WL_TRY(sync_u(s));
     if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
       WL_TRY(wl::conv_diff_z(f, uadv, nullptr, nullptr, nullptr, G, d.nu, d.scheme, 0.f, 0.f, 1.f, s));
       return wl::conv_q1(sigma, uadv, G, d.nu, d.perdir_mask, d.scheme, s);
@@ -219,9 +242,10 @@ struct wl_sim {
     if (us && !d.has_body && !forcing) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
       ProfScope pc(WL_PROF_CONVDIFF, s);
       if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
+        WL_TRY(sync_u(s));
         WL_TRY(wl::conv_diff_z(f, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
         WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
-      } else WL_TRY(wl::conv_diff_bdim(f, u0, sigma, u0, mu0, u, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 0.f, 1.f, mg->lv[0].cl, s));
+      } else WL_TRY(conv_fused(u0, u, 0.f, 1.f, s));
     } else {
       { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
       if (forcing) WL_TRY(wl::accelerate(f, G, acc0, s));                                  // accelerate!(f,t₀,g,uBC)
@@ -235,9 +259,10 @@ struct wl_sim {
     if (us && !d.has_body && !forcing) {   // the advecting field is u itself: write the new u to the spare array and swap
       { ProfScope pc(WL_PROF_CONVDIFF, s);
         if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
+          WL_TRY(sync_u(s));
           WL_TRY(wl::conv_diff_z(f, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
           WL_TRY(wl::conv_q1(sigma, u, G, d.nu, d.perdir_mask, d.scheme, s));
-        } else WL_TRY(wl::conv_diff_bdim(f, u, sigma, u0, mu0, us, G, d.nu, d.perdir_mask, d.scheme, dt.back(), 1.f, 0.5f, mg->lv[0].cl, s)); }
+        } else WL_TRY(conv_fused(u, us, 1.f, 0.5f, s)); }
       std::swap(u, us);
       return bc_u(s);
     }
@@ -251,6 +276,7 @@ struct wl_sim {
   int project(float w, hipStream_t s, bool with_cfl = false) {                           // mom_project! :223-232
     const float dtl = w * dt.back();
     cfl_done = false;
+    WL_TRY(sync_u(s));                                                                     // div(u) reads the halo planes
     if (ps && use_fuse_p && !d.perdir_mask) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
@@ -260,7 +286,8 @@ struct wl_sim {
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
       if (with_cfl && use_fuse_cfl && us && !d.exitBC) {   // + flux_out and its maximum; projected u lands in the spare array
         WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s));
-        std::swap(u, us); cfl_done = true;
+        WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
+        std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
       } else WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
       std::swap(p, ps); l0.x = p;
       return bc_u(s);
@@ -272,9 +299,8 @@ struct wl_sim {
     return bc_u(s);
   }
   int cfl(hipStream_t s) {                                                               // CFL :234-237
-    if (!cfl_done) WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s));
+    if (!cfl_done) { WL_TRY(sync_u(s)); WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s)); WL_TRY(wl::combine_results(comm, mg->ws, s)); }   // max over ranks
     cfl_done = false;
-    WL_TRY(wl::combine_results(comm, mg->ws, s));                                        // max over ranks
     float mx; WL_TRY(wl::read_results(mg->ws, nullptr, 0, &mx, 1, s));
     dt.push_back(std::fmin(10.f, 1.0f / (mx + 5 * d.nu)));
     return 0;
@@ -283,8 +309,8 @@ struct wl_sim {
     ProfScope pstep(WL_PROF_STEP, s);
     // u⁰ .= u ; scale_u!(a,0): when the handle owns both arrays the copy is a pointer swap — the predictor overwrites
     // every interior cell of u (BDIM! with pre=0) and BC! every ghost cell, so nothing of the old u survives anyway.
-    if (swap_ok) std::swap(u, u0);
-    else WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s));   // u⁰ .= u
+    if (swap_ok) std::swap(u, u0);   // (an exchange still in flight belongs to the array that is now u⁰ — the predictor's advecting field)
+    else { WL_TRY(sync_u(s)); WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s)); }   // u⁰ .= u
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s));
     WL_TRY(correct(s));
@@ -380,6 +406,7 @@ int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm) { r
 int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
 float* wl_sim_field(wl_sim* s, const char* name) {
   const std::string n(name);
+  (void)s->sync_u(0);        // the caller is about to read or write the arrays: finish an exchange that is still in flight
   if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") return s->p;
   if (n == "sigma") return s->sigma; if (n == "V") return s->V; if (n == "mu0") return s->mu0; if (n == "mu1") return s->mu1;
   return nullptr;
@@ -405,6 +432,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
+  if (n == "overlap") { WL_TRY(s->sync_u(0)); s->use_overlap = value != 0; return 0; }
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
@@ -430,7 +458,7 @@ double wl_sim_time(const wl_sim* s) { float t = 0.f; for (size_t k = 0; k + 1 < 
 int wl_sim_phase(wl_sim* s, int phase, void* st) {
   hipStream_t q = wl_stream(st);
   switch (phase) {
-    case 0: WL_HIP(hipMemcpyAsync(s->u0, s->u, sizeof(float) * (size_t)s->G.cs * s->d.D, hipMemcpyDeviceToDevice, q)); return wl::scale_u(s->u, s->G, 0.f, q);
+    case 0: WL_TRY(s->sync_u(q)); WL_HIP(hipMemcpyAsync(s->u0, s->u, sizeof(float) * (size_t)s->G.cs * s->d.D, hipMemcpyDeviceToDevice, q)); return wl::scale_u(s->u, s->G, 0.f, q);
     case 1: return s->predict(q);
     case 2: return s->project(1.f, q);
     case 3: return s->correct(q);
