@@ -21,7 +21,7 @@ def w():
 
 def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
     sims = {}
-    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0}), ("zmarch", {"convz": 1}), ("convm", {"convm": 1})):
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1}), ("zmarch", {"convz": 1}), ("convm", {"convm": 1})):
         s = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
         for k, v in opts.items():
             s.set_option(k, v)

@@ -162,6 +162,7 @@ def test_fused_phases_match_oracle(w, oracle):
     N = 16
     so = oracle.Simulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, u0=tgv3d(N), T=np.float32)
     sg = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, u0=so.u.copy(order="F"))
+    sg.set_option("store_f", 1)      # materialise the intermediates f and z (the time-step path itself never reads them again)
     for ph in range(6):
         so.phase(ph); sg.phase_(ph)
         tol = 0 if ph in (0, 1, 3) else 2e-5
@@ -286,6 +287,7 @@ def test_zmarching_conv_diff_is_bit_identical(w, oracle, dims, body):
         if body:
             sg.set_field("mu0", so.field("mu0")); sg.set_field("mu1", so.field("mu1")); sg.update_()
         sg.set_option("convz", convz)
+        sg.set_option("store_f", 1)
         out = []
         for ph in (0, 1, 2, 3):
             sg.phase_(ph)

@@ -136,7 +136,7 @@ __device__ __forceinline__ void cd_store(const GridX& g, float* __restrict__ r, 
     const long oa = (long)a * g.cs + o;
     if (!fuse) { r[oa] = out[a]; continue; }
     const float fn = bd.u0[oa] + bd.dt * out[a] - 0.f;
-    r[oa] = fn;
+    if (r) r[oa] = fn;                       // f itself is optional: nothing on the time-step path reads it again
     if (in) {
       const float m0 = bd.cl_on ? wl::wl_cl_coef(I[a], N[a], bd.cl_c[a]) : bd.mu0[oa];     // μ₀ on a verified NoBody field
       const float xx = (0.f / 2 + 0.f) + m0 * fn;

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, fl
       if (!store) break;
       const long oa = (long)a * g.cs + o;
       const float fn = bd.u0[oa] + bd.dt * out[a] - 0.f;
-      r[oa] = fn;
+      if (r) r[oa] = fn;
       if (in) {
         const float m0 = bd.cl_on ? wl::wl_cl_coef(I[a], N[a], bd.cl_c[a]) : bd.mu0[oa];     // μ₀ on a verified NoBody field
         const float xx = (0.f / 2 + 0.f) + m0 * fn;
@@ -487,7 +487,7 @@ int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, 
 #undef WL_Q1
   WL_LAUNCH_CHECK(); return 0;
 }
-// conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: f and u_out written, u_out must not alias u_adv
+// conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: u_out (and f unless f == NULL) written, u_out must not alias u_adv
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
                    float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka, int kb, bool q1) {
   if (u_out == u_adv) { wl_set_error("conv_diff_bdim: output aliases the advecting field"); return WL_EINVAL; }

@@ -103,7 +103,7 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
         dv += u[o + 1] - u[o];
         dv += u[g.cs + o + g.sy] - u[g.cs + o];
         if (D == 3) dv += uzkp - uzk;
-        z[o] = dv;
+        if (z) z[o] = dv;            // b.z itself is optional: solver! reads it only through this residual
         // D (and iD==0 ⇔ D==0) recomputed from the face coefficients the stencil needs anyway: same operation order as
         // set_diag! (src/Poisson.jl:43-55), same bits as the stored arrays, 8 B/cell less traffic
         float lz = 0.f, lzp = 0.f;

@@ -208,8 +208,10 @@ struct wl_sim {
     return wl::halo(comm, u, G, d.D, 2, s);
   }
   // fused conv_diff!+BDIM! (NoBody): interior planes first when the advecting field's halo is still in flight
+  bool store_f = false;      // the fused paths materialise the intermediates f = u⁰+Δt·r and z = ∇·u only on request: nothing on the time-step path reads them again
   int conv_fused(const float* uadv, float* uout, float pre, float post, hipStream_t s) {
     const wl::ConstL& cl = mg->lv[0].cl;
+    float* f = store_f ? this->f : nullptr;
     if (u_pending && G.D == 3 && G.k1 - G.k0 > 4) {
       WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k0 + 2, G.k1 - 2, false));
       WL_TRY(sync_u(s));
@@ -280,7 +282,7 @@ struct wl_sim {
     if (ps && use_fuse_p && !d.perdir_mask) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
-      { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(sigma, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s)); }
+      { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s)); }
       std::swap(p, ps); l0.x = p;
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
@@ -432,6 +434,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
+  if (n == "store_f") { s->store_f = value != 0; return 0; }
   if (n == "overlap") { WL_TRY(s->sync_u(0)); s->use_overlap = value != 0; return 0; }
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
