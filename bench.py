@@ -83,48 +83,9 @@ def cpu_baseline(n=128, warm=2, steps=None, budget_s=12.0):
             "seconds": el}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=512, help="interior cells per side of the TGV box")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0)
-    args = ap.parse_args()
-
-    import torch
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    import waterlily_jl_amd as w
+def read_prof(lib):
+    """HIP-event timings recorded by the library on its launch stream (wl_prof_*), per named slot"""
     from waterlily_jl_amd._lib import check
-    lib = w.lib()
-    check(lib.wl_init(local_rank))
-
-    N = args.size
-    if world > 1:
-        from waterlily_jl_amd import slab
-        return slab.bench_main(args, world, rank, local_rank)
-
-    sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
-    for opt in ("convz", "fused_smoother", "fuse_p", "constl", "pair", "convm", "fuse_cfl", "store_f"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
-        if os.environ.get("WL_OPT_" + opt) is not None:
-            sim.set_option(opt, int(os.environ["WL_OPT_" + opt]))
-    for _ in range(args.warmup):
-        sim.mom_step_()
-    sim.sync()
-    n_warm = len(sim.pois_n)
-    check(lib.wl_prof_enable(1))
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.mom_step_()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
     prof = {}
     names = {0: "gs_sweep", 1: "smooth", 2: "jacobi", 3: "conv_diff", 4: "residual", 5: "bdim", 6: "prolong_increment", 7: "coarse_levels", 8: "mom_step",
              9: "gsrb_A", 10: "gsrb_B"}
@@ -132,11 +93,11 @@ def main():
         cnt, tot = C.c_int(), C.c_double()
         check(lib.wl_prof_read(slot, C.byref(cnt), C.byref(tot)))
         prof[nm] = {"launches": cnt.value, "avg_ms": (tot.value / cnt.value) if cnt.value else None, "total_ms": tot.value}
-    check(lib.wl_prof_enable(0))
-    ncell = float(N) ** 3
-    pn = sim.pois_n[n_warm:]
-    const0 = bool(sim.const_levels()[0])
-    kind0 = sim.smoother_kinds()[0]
+    return prof
+
+
+def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
+    """`roofline` object for the finest-level smooth! of THIS rank (ncell = the cells its launches process)"""
     # The roofline kernel: the finest-level smooth! (GaussSeidelRB!, it=4) as executed — the temporally blocked kernel pair A+B.
     if not prof["gsrb_B"]["launches"]:   # experiments with the blocked smoother switched off: report the plain colour sweep instead
         prof["gsrb_B"], prof["gsrb_A"] = prof["gs_sweep"], prof["gs_sweep"]
@@ -149,7 +110,7 @@ def main():
     gbs = lambda by, ms: by * ncell / (ms * 1e-3) / 1e9
     traffic, tsrc, tper = None, None, {}
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
+    if use_traffic and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("size") == N and {"A", "B"} <= set(tj.get("kernels", {})):
@@ -179,6 +140,58 @@ def main():
                   "traffic": tper.get("B")},
         },
     }
+    return roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=512, help="interior cells per side of the TGV box")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("WL_BENCH_ONE_GPU"):      # rehearsal of the multi-rank path on a one-GPU box (with WL_DIST_BACKEND=gloo)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    import waterlily_jl_amd as w
+    from waterlily_jl_amd._lib import check
+    lib = w.lib()
+    check(lib.wl_init(local_rank))
+
+    N = args.size
+    if world > 1:
+        from waterlily_jl_amd import slab
+        return slab.bench_main(args, world, rank, local_rank, read_prof=read_prof, build_roofline=build_roofline)
+
+    sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+    for opt in ("convz", "fused_smoother", "fuse_p", "constl", "pair", "convm", "fuse_cfl", "store_f"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
+        if os.environ.get("WL_OPT_" + opt) is not None:
+            sim.set_option(opt, int(os.environ["WL_OPT_" + opt]))
+    for _ in range(args.warmup):
+        sim.mom_step_()
+    sim.sync()
+    n_warm = len(sim.pois_n)
+    check(lib.wl_prof_enable(1))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sim.mom_step_()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    prof = read_prof(lib)
+    check(lib.wl_prof_enable(0))
+    ncell = float(N) ** 3
+    pn = sim.pois_n[n_warm:]
+    roof = build_roofline(prof, ncell, bool(sim.const_levels()[0]), sim.smoother_kinds()[0], N, use_traffic=True)
     out = {
         "metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": ncell * args.steps / el, "unit": "cells*steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,

@@ -223,7 +223,7 @@ def make_comm(dist, device, prefer="rccl"):
     return CallbackComm(dist)
 
 
-def bench_main(args, world, rank, local_rank):
+def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=None):
     """bench.py --gpus N (N>1): the same 512³ TGV cut into N z-slabs (strong scaling), one process per GPU."""
     import torch
     import torch.distributed as dist
@@ -237,6 +237,8 @@ def bench_main(args, world, rank, local_rank):
         sim.mom_step_()
     sim.sync()
     n_warm = len(sim.pois_n)
+    if rank == 0 and read_prof is not None:
+        check(lib().wl_prof_enable(1))          # HIP-event pairs around rank 0's finest-level smoother kernels
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -248,6 +250,18 @@ def bench_main(args, world, rank, local_rank):
     t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
+    roof = None
+    if rank == 0 and read_prof is not None:
+        try:
+            prof = read_prof(lib())
+            check(lib().wl_prof_enable(0))
+            mg = lib().wl_sim_pois(sim._h)
+            g = sim.grid
+            ncell_local = float(N) * float(N) * float(g.k1 - g.k0)
+            roof = build_roofline(prof, ncell_local, bool(lib().wl_mg_level_is_const(mg, 0)), int(lib().wl_mg_smoother_kind(mg, 0)), N, use_traffic=False)
+            roof["scope"] = f"rank 0 of {world}: its {g.k1 - g.k0} planes of the finest level"
+        except Exception as e:   # noqa: BLE001 — the throughput line must not depend on the optional roofline block
+            roof = {"error": repr(e)}
     if rank == 0:
         pn = sim.pois_n[n_warm:]
         out = {"metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": float(N) ** 3 * args.steps / el, "unit": "cells*steps/s",
@@ -256,7 +270,7 @@ def bench_main(args, world, rank, local_rank):
                "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false, {world} z-slabs",
                           "size": N, "parallelism": f"zslab{world}", "transport": type(comm).__name__, "mean_pois_n": float(sum(pn)) / max(1, len(pn)),
                           "dt_last": float(sim.dt[-1])},
-               "roofline": None, "cpu_baseline": None}
+               "roofline": roof, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     dist.barrier()
     del sim
