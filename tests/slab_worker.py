@@ -96,6 +96,33 @@ def main():
         del sim
         comm.destroy()
         print(f"rank {rank}: gpu_sim ok", flush=True)
+    elif mode == "gpu_exit":
+        # convective exit (exitBC!) + immersed sphere on slabs: the x-exit face is shared by all ranks, its means are global
+        torch.cuda.set_device(0)
+        dims = tuple(int(v) for v in sys.argv[2].split("x"))
+        steps = int(sys.argv[3])
+        comm = slab.CallbackComm(dist)
+        R, c = dims[1] / 8.0, (dims[0] / 4.0, dims[1] / 2.0 - 1, dims[2] / 2.0 - 1)
+        nu = 2 * R / 250.0
+        sim = slab.SlabSimulation(comm, dims, (1.0, 0.0, 0.0), 2 * R, U=1, nu=nu, has_body=True, exitBC=True)
+        sim.measure_sphere_(c, R)
+        ref = None
+        if rank == 0:
+            ref = w.FusedSimulation(dims, (1.0, 0.0, 0.0), 2 * R, U=1, nu=nu, has_body=True, exitBC=True)
+            ref.measure_sphere_(c, R)
+        for s in range(steps):
+            sim.mom_step_()
+            u = sim.gather_field("u", dist)
+            if rank == 0:
+                ref.mom_step_()
+                du = np.abs(u - ref.field("u")).max()
+                print(f"step {s}: max|du|={du:.3e} n_slab={sim.pois_n[-2:]} n_ref={ref.pois_n[-2:]}", flush=True)
+                assert sim.pois_n == ref.pois_n
+                assert du < 5e-5, du
+        dist.barrier()
+        del sim
+        comm.destroy()
+        print(f"rank {rank}: gpu_exit ok", flush=True)
     elif mode == "gpu_rccl1":
         # RCCL transport smoke test with the ranks one box offers (1): dlopen of librccl.so.1 shared with torch,
         # unique-id broadcast, ncclCommInitRank, ncclAllGather on the stream, a whole slab step through the RCCL comm object.

@@ -36,6 +36,24 @@ def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
         assert np.array_equal(sims[tag][1], sims["fast"][1]), tag
 
 
+def test_benchmark_size_fast_path_equals_plain_path_bitwise(w):
+    """512³ — the size bench.py times: one mom_step! through the default kernels (pair smoother with fused prolongation, constant
+    coefficients, fused projection head/tails, intermediates not stored) and through the one-kernel-per-pass general kernels."""
+    import gc
+    res = {}
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1})):
+        s = w.FusedSimulation((512, 512, 512), (0, 0, 0), 512, U=1, nu=512 / 1600.0, ic="tgv")
+        for k, v in opts.items():
+            s.set_option(k, v)
+        s.mom_step_()
+        res[tag] = (s.field("u"), s.field("p"), s.pois_n, s.dt)
+        del s
+        gc.collect()
+    assert res["fast"][2] == res["plain"][2] and res["fast"][3] == res["plain"][3]
+    assert np.array_equal(res["fast"][0], res["plain"][0])
+    assert np.array_equal(res["fast"][1], res["plain"][1])
+
+
 def test_projection_is_divergence_free_and_energy_decays(w):
     s = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
     ke = []

@@ -162,6 +162,39 @@ __global__ void k_exit_facesum(GridX g, const float* __restrict__ u, double* __r
     if (mode == 0) out[0] = (double)mean; else out[1] = (double)(mean - (float)out[0]);
   }
 }
+// z-slab variant: every rank sums its owned planes of the face (res_d[slot], summed over ranks by combine_results), then
+// k_exit_mean turns the global sum into the mean exactly as above (float division by the global face size)
+template <int D>
+__global__ void k_exit_facesum_part(GridX g, const float* __restrict__ u, double* __restrict__ out, int mode) {
+  const int ny = g.ny - 2, nz = g.k1 - g.k0;
+  const long cnt = (long)ny * nz;
+  const int ix = (mode == 0) ? 1 : g.nx - 1;
+  double acc = 0.0;
+  for (long q = threadIdx.x; q < cnt; q += blockDim.x) {
+    const int j = 1 + (int)(q % ny), k = g.k0 + (int)(q / ny);
+    acc += (double)u[ix + (long)j * g.sy + (long)k * g.sz];
+  }
+  __shared__ double sh[16];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += sh[w]; *out = s; }
+}
+__global__ void k_exit_mean(const double* __restrict__ gsum, double* __restrict__ sc, long cnt, int mode) {
+  const float mean = (float)(*gsum) / (float)cnt;
+  if (mode == 0) sc[0] = (double)mean; else sc[1] = (double)(mean - (float)sc[0]);
+}
+template <int D>
+__global__ void k_exit_update_slab(GridX g, float* __restrict__ u, const float* __restrict__ u0, const double* __restrict__ sc, float dt, int mode) {
+  const int ny = g.ny - 2;
+  const long cnt = (long)ny * (g.k1 - g.k0);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  const int j = 1 + (int)(q % ny), k = g.k0 + (int)(q / ny);
+  const long o = (g.nx - 1) + (long)j * g.sy + (long)k * g.sz;
+  if (mode == 0) { const float U = (float)sc[0]; u[o] = u0[o] - U * dt * (u0[o] - u0[o - 1]); }
+  else u[o] -= (float)sc[1];
+}
 template <int D>
 __global__ void k_exit_update(GridX g, float* __restrict__ u, const float* __restrict__ u0, const double* __restrict__ sc, float dt, int mode) {
   const int ny = g.ny - 2;
@@ -189,11 +222,12 @@ struct wl_sim {
   bool swap_ok = false;      // u and u⁰ are handle-owned and every ghost of u is rewritten by BC! (no exitBC)
   float* ps = nullptr;       // spare pressure array (out-of-place x·dt and x/dt around the solve; two swaps restore p's identity)
   bool use_fuse_p = true;
+  double* exit_sc = nullptr; // exitBC! on slabs: global face means (device)
   bool forcing = false;      // uniform g(i,t)+dU(i,t)/dt supplied by the host for the current step (accelerate!, src/Flow.jl:69-73)
   float acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};   // at t₀ (predictor) and t₁ (corrector)
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
-  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); }
+  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); }
 
   // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
   // On slabs the exchange runs on the communicator's own stream; the compute stream waits for it (sync_u) only where the halo
@@ -321,6 +355,20 @@ struct wl_sim {
   }
 };
 int wl_sim::exit_bc(hipStream_t s) {
+  if (comm) {   // z-slabs: the exit face is shared by all ranks — global means from per-rank sums (one 128-byte all-gather each)
+    if (!exit_sc) WL_HIP(hipMalloc((void**)&exit_sc, 2 * sizeof(double)));
+    WL_TRY(sync_u(s));
+    const long gcnt = (long)(G.ny - 2) * (G.gnz - 2), lcnt = (long)(G.ny - 2) * (G.k1 - G.k0);
+    const unsigned nbl = (unsigned)((lcnt + WL_BLOCK - 1) / WL_BLOCK);
+    for (int mode = 0; mode < 2; mode++) {
+      hipLaunchKernelGGL(k_exit_facesum_part<3>, dim3(1), dim3(1024), 0, s, G, (const float*)u, mg->ws.res_d + 4, mode);
+      WL_TRY(wl::combine_results(comm, mg->ws, s));
+      hipLaunchKernelGGL(k_exit_mean, dim3(1), dim3(1), 0, s, (const double*)(mg->ws.res_d + 4), exit_sc, gcnt, mode);
+      hipLaunchKernelGGL(k_exit_update_slab<3>, dim3(nbl), dim3(WL_BLOCK), 0, s, G, u, (const float*)u0, (const double*)exit_sc, dt.back(), mode);
+    }
+    WL_LAUNCH_CHECK();
+    return wl::halo(comm, u, G, d.D, 2, s);      // the exit face changed after BC!'s exchange
+  }
   double* sc = mg->ws.res_d + 4;
   const long cnt = (long)(G.ny - 2) * (G.D == 3 ? (G.nz - 2) : 1);
   const unsigned nb = (unsigned)((cnt + WL_BLOCK - 1) / WL_BLOCK);
@@ -364,7 +412,6 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   wl_sim* s = new wl_sim(); s->d = *desc; s->comm = slab ? comm : nullptr;
   int32_t ng[3] = {desc->dims[0] + 2, desc->dims[1] + 2, desc->D == 3 ? desc->dims[2] + 2 : 1};
   if (slab) {
-    if (desc->exitBC) { delete s; wl_set_error("exitBC on z-slabs is not supported this round"); return WL_EINVAL; }
     if (desc->u || desc->u0 || desc->f || desc->p || desc->sigma || desc->V || desc->mu0 || desc->mu1) { delete s; wl_set_error("slab simulations own their arrays"); return WL_EINVAL; }
     const int rc = wl_grid_slab(&s->g, desc->D, ng, comm->rank, comm->size, 3);   // 3 ghost planes: QUICK needs 2, kernel B of the blocked smoother 3
     if (rc != 0) { delete s; return rc; }

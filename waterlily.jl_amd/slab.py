@@ -127,7 +127,7 @@ class RcclComm:
 class SlabSimulation:
     """Simulation on a z-slab (wl_sim_create_slab): same step as FusedSimulation, fields distributed along z."""
 
-    def __init__(self, comm, dims, uBC, L, U=None, dt=0.25, nu=0.0, perdir=(), lam=0, has_body=False, ic="uBC"):
+    def __init__(self, comm, dims, uBC, L, U=None, dt=0.25, nu=0.0, perdir=(), lam=0, has_body=False, ic="uBC", exitBC=False):
         D = 3
         assert len(dims) == 3
         if U is None:
@@ -140,7 +140,7 @@ class SlabSimulation:
             d.dims[k] = self.dims[k]
             d.uBC[k] = float(uBC[k])
         d.nu, d.dt0 = float(nu), float(dt)
-        d.perdir_mask, d.exitBC, d.scheme, d.has_body = perdir_mask(perdir), 0, int(lam), int(bool(has_body))
+        d.perdir_mask, d.exitBC, d.scheme, d.has_body = perdir_mask(perdir), int(bool(exitBC)), int(lam), int(bool(has_body))
         h = C.c_void_p()
         check(lib().wl_sim_create_slab(C.byref(h), C.byref(d), comm.handle))
         self._h = h
@@ -161,6 +161,11 @@ class SlabSimulation:
 
     def mom_step_(self):
         check(lib().wl_sim_mom_step(self._h, None))
+
+    def measure_sphere_(self, center, R, eps=1.0):
+        """measure!(sim) for AutoBody(|x-c|-R) in GLOBAL coordinates: closed form on device + update!(pois)"""
+        c = (C.c_float * 3)(*[float(v) for v in center])
+        check(lib().wl_sim_measure_sphere(self._h, c, float(R), float(eps), None))
 
     def sync(self):
         check(lib().wl_stream_sync(None))
