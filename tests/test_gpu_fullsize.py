@@ -21,7 +21,7 @@ def w():
 
 def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
     sims = {}
-    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1}), ("zmarch", {"convz": 1}), ("convm", {"convm": 1})):
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1, "tail": 0}), ("zmarch", {"convz": 1}), ("convm", {"convm": 1})):
         s = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
         for k, v in opts.items():
             s.set_option(k, v)
@@ -41,7 +41,7 @@ def test_benchmark_size_fast_path_equals_plain_path_bitwise(w):
     coefficients, fused projection head/tails, intermediates not stored) and through the one-kernel-per-pass general kernels."""
     import gc
     res = {}
-    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1})):
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1, "tail": 0})):
         s = w.FusedSimulation((512, 512, 512), (0, 0, 0), 512, U=1, nu=512 / 1600.0, ic="tgv")
         for k, v in opts.items():
             s.set_option(k, v)

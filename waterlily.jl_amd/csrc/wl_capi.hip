@@ -193,6 +193,23 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));                                      // perBC!(ϵ) inside increment! :101
   return wl::increment(p.r, p.x, p.eps, p.L, p.D, p.x_, w, s);
 }
+// the levels first..end as one launch: "if (first is not the coarsest) Vcycle!(first); smooth!(first)"
+bool wl_mg::tail_ok(int first) const {
+  if (!use_tail || perdir || first < 1 || first >= (int)lv.size() || (int)lv.size() - first > WL_TAIL_MAXLV) return false;
+  if (lv[(size_t)first].g.D != 3 || lv[(size_t)first].x_.cs > WL_TAIL_CELLS) return false;
+  for (size_t l = (size_t)first; l < lv.size(); l++) if (lv[l].dist || lv[l].pend) return false;
+  return true;
+}
+int wl_mg::tail(int first, float w, hipStream_t s) {
+  wl::TailLevelHost h[WL_TAIL_MAXLV];
+  const int n = (int)lv.size() - first;
+  for (int q = 0; q < n; q++) {
+    const Level& v = lv[(size_t)(first + q)];
+    h[q] = wl::TailLevelHost{v.x_, v.L, v.D, v.iD, v.x, v.eps, v.r, 0, 0, 0};
+    if (q + 1 < n) { const Level& c = lv[(size_t)(first + q + 1)]; h[q].cx = c.g.nx < v.g.nx; h[q].cy = c.g.ny < v.g.ny; h[q].cz = c.g.gnz < v.g.gnz; }
+  }
+  return wl::vcycle_tail(h, n, w, s);
+}
 int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                            // Vcycle! :88-101
   Level& fine = lv[(size_t)l]; Level& coarse = lv[(size_t)l + 1];
   // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
@@ -216,8 +233,11 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
       WL_TRY(wl::allgather_planes(comm, coarse.r, coarse.view, 1, s));
     } else WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
     WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
-    if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s, true));                         // its last step may be deferred into the smooth! below
-    WL_TRY(smooth(l + 1, 4, w, s));
+    if (tail_ok(l + 1)) WL_TRY(tail(l + 1, w, s));                                         // everything below in one launch
+    else {
+      if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s, true));                       // its last step may be deferred into the smooth! below
+      WL_TRY(smooth(l + 1, 4, w, s));
+    }
     WL_TRY(halo(coarse, coarse.x, 1, s, pair_slab(fine) ? 2 : 1));                         // prolongation reads the coarse cells under my halo planes
   }
   // prolongate!(fine.ϵ,coarse.x); increment!(fine;ω): the caller's next operation is smooth!(fine;ω) with the same ω — when that
@@ -465,7 +485,7 @@ int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 
   return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
 }
 int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
-int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); return 0; }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

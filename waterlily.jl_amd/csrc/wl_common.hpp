@@ -229,6 +229,11 @@ int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const 
 int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s);
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s);
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
+// coarse tail of the V-cycle in one launch (wl_poisson.hip)
+#define WL_TAIL_MAXLV 8
+#define WL_TAIL_CELLS 8192
+struct TailLevelHost { GridX g; const float* L; const float* D; const float* iD; float* x; float* eps; float* r; int cx, cy, cz; };
+int vcycle_tail(const TailLevelHost* lv, int n, float w, hipStream_t s);
 int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* L, const float* Dg, const float* iD, const GridX& g, float a, int more, const RedWs& ws, hipStream_t s);
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s);

@@ -22,6 +22,9 @@ struct wl_mg {
   bool use_constl = true;   // allow the constant-coefficient specialisations where the pattern is verified
   bool store_eps = true;    // the blocked smoother also stores the final ϵ (p.ϵ of the reference); the mom_step! composite turns it off
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
+  bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
+  bool tail_ok(int first) const;
+  int tail(int first, float w, hipStream_t s);
   float* slab = nullptr;    // owns r,ϵ,D,iD of every level and L,x,z of the coarse levels
   void* red = nullptr;      // reduction workspace
   RedWs ws;

@@ -515,6 +515,89 @@ __global__ void k_prolong_increment(GridX gf, GridX gc, float* __restrict__ r, f
   x[o] = x[o] + w * e0;
   if (write_eps) eps[o] = e0;
 }
+// ---- the coarse tail of Vcycle! in ONE launch ------------------------------------------------------------------------
+// Levels of at most WL_TAIL_CELLS cells cost nothing but launch latency (≈9 launches of ≈5 µs per level and V-cycle).  One
+// 1024-thread workgroup walks all of them: Jacobi!, restrict!, x_c=0 going down; smooth! at the bottom; prolongate!+increment!,
+// smooth! coming up — phases separated by workgroup barriers, the arrays stay in L2.  Every phase executes the statements of the
+// kernel it replaces (k_gs_init, k_increment, k_restrict, k_prolong_increment, k_gs_sweep) ⇒ bit-identical.  3-D, non-periodic,
+// non-distributed levels only.
+struct TailLevel { GridX g; const float* L; const float* D; const float* iD; float* x; float* eps; float* r; int cx, cy, cz; };
+struct TailArgs { int n; float w; TailLevel lv[WL_TAIL_MAXLV]; };
+
+template <class F>
+__device__ __forceinline__ void tail_inside(const GridX& g, F fn) {
+  const int nxi = g.nx - 2, nyi = g.ny - 2, nzi = g.nz - 2;
+  const int n = nxi * nyi * nzi;
+  for (int c = threadIdx.x; c < n; c += blockDim.x) {
+    const int i = 1 + c % nxi, t = c / nxi, j = 1 + t % nyi, k = 1 + t / nyi;
+    fn(i, j, k, (long)i + (long)j * g.sy + (long)k * g.sz);
+  }
+}
+__device__ __forceinline__ void tail_smooth(const TailLevel& v, float w) {     // GaussSeidelRB!(it=4,ω)   src/Poisson.jl:141-148
+  const GridX& g = v.g;
+  tail_inside(g, [&](int, int, int, long o) { v.eps[o] = v.r[o] * v.iD[o]; });
+  __syncthreads();
+  for (int kk0 = 1; kk0 <= 4; kk0++) {
+    tail_inside(g, [&](int i, int j, int k, long o) {
+      if (((i + j + k + 3 + kk0) & 1) == 0) return;
+      if (k + 1 > 2 * (g.gnz / 2) - 1) return;                                  // quirk Q4
+      float s = v.r[o];
+      s -= (v.eps[o - 1] * v.L[o] + v.eps[o + 1] * v.L[o + 1]);
+      s -= (v.eps[o - g.sy] * v.L[g.cs + o] + v.eps[o + g.sy] * v.L[g.cs + o + g.sy]);
+      s -= (v.eps[o - g.sz] * v.L[2 * g.cs + o] + v.eps[o + g.sz] * v.L[2 * g.cs + o + g.sz]);
+      v.eps[o] = s * v.iD[o];
+    });
+    __syncthreads();
+  }
+  tail_inside(g, [&](int, int, int, long o) {
+    v.r[o] = v.r[o] - w * Ax<3>(g, o, v.L, v.D, v.eps);
+    v.x[o] = v.x[o] + w * v.eps[o];
+  });
+  __syncthreads();
+}
+__global__ void __launch_bounds__(1024) k_vcycle_tail(TailArgs a) {
+  // ---- down: Jacobi!(fine); restrict!(coarse.r, fine.r); coarse.x = 0            src/MultiLevelPoisson.jl:92-95
+  for (int l = 0; l + 1 < a.n; l++) {
+    const TailLevel& f = a.lv[l]; const TailLevel& c = a.lv[l + 1];
+    tail_inside(f.g, [&](int, int, int, long o) { f.eps[o] = f.r[o] * f.iD[o]; });
+    __syncthreads();
+    tail_inside(f.g, [&](int, int, int, long o) {
+      f.r[o] = f.r[o] - 1.f * Ax<3>(f.g, o, f.L, f.D, f.eps);
+      f.x[o] = f.x[o] + 1.f * f.eps[o];
+    });
+    __syncthreads();
+    for (long q = threadIdx.x; q < c.g.cs; q += blockDim.x) c.x[q] = 0.f;
+    tail_inside(c.g, [&](int i, int j, int k, long o) {
+      const int fi = f.cx ? 2 * i - 1 : i, fj = f.cy ? 2 * j - 1 : j, fk = f.cz ? 2 * k - 1 : k;
+      float s = 0.f;
+      for (int cc = 0; cc <= f.cz; cc++)
+        for (int bb = 0; bb <= f.cy; bb++)
+          for (int aa = 0; aa <= f.cx; aa++) s += f.r[(long)(fi + aa) + (long)(fj + bb) * f.g.sy + (long)(fk + cc) * f.g.sz];
+      c.r[o] = s;
+    });
+    __syncthreads();
+  }
+  // ---- bottom and up: smooth!(coarse) ; prolongate!+increment!(fine;ω) ; ... ; smooth!(first level)            :96-100
+  for (int l = a.n - 1; l >= 0; l--) {
+    const TailLevel& v = a.lv[l];
+    if (l + 1 < a.n) {
+      const TailLevel& c = a.lv[l + 1];
+      const GridX& gf = v.g; const GridX& gc = c.g;
+      tail_inside(gf, [&](int i, int j, int k, long o) {
+        auto E = [&](int ii, int jj, int kk) -> float { return c.x[down_off<3>(gf, gc, ii, jj, kk, v.cx, v.cy, v.cz)]; };
+        const float e0 = E(i, j, k);
+        float s = e0 * v.D[o];
+        s += (E(i - 1, j, k) * v.L[o] + E(i + 1, j, k) * v.L[o + 1]);
+        s += (E(i, j - 1, k) * v.L[gf.cs + o] + E(i, j + 1, k) * v.L[gf.cs + o + gf.sy]);
+        s += (E(i, j, k - 1) * v.L[2 * gf.cs + o] + E(i, j, k + 1) * v.L[2 * gf.cs + o + gf.sz]);
+        v.r[o] = v.r[o] - a.w * s;
+        v.x[o] = v.x[o] + a.w * e0;
+      });
+      __syncthreads();
+    }
+    tail_smooth(v, a.w);
+  }
+}
 // restrictL!  a[I,i] = restrictL(I,i,b,c)   src/MultiLevelPoisson.jl:9-11,20-26,45  (BC!(a,0) applied afterwards by bc_vec)
 template <int D>
 __global__ void k_restrictL(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
@@ -658,6 +741,14 @@ int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, 
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s) {
   if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
   else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// if (levels below `first` exist) Vcycle!(first); smooth!(first)  — for the levels handed over in `lv` (coarsening flags in lv[l].c*)
+int vcycle_tail(const TailLevelHost* lv, int n, float w, hipStream_t s) {
+  if (n < 1 || n > WL_TAIL_MAXLV) { wl_set_error("vcycle_tail: bad level count"); return WL_EINVAL; }
+  TailArgs a; a.n = n; a.w = w;
+  for (int l = 0; l < n; l++) a.lv[l] = TailLevel{lv[l].g, lv[l].L, lv[l].D, lv[l].iD, lv[l].x, lv[l].eps, lv[l].r, lv[l].cx, lv[l].cy, lv[l].cz};
+  hipLaunchKernelGGL(k_vcycle_tail, dim3(1), dim3(1024), 0, s, a);
   WL_LAUNCH_CHECK(); return 0;
 }
 // one stage of pcg! ; stages 0-2 leave their dot product in ws.res_d[0]

@@ -481,6 +481,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fused_smoother") { s->mg->use_fused = value != 0; return 0; }
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
+  if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
   if (n == "store_f") { s->store_f = value != 0; return 0; }
   if (n == "overlap") { WL_TRY(s->sync_u(0)); s->use_overlap = value != 0; return 0; }
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
