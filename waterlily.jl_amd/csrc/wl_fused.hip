@@ -14,6 +14,8 @@
 // (true for the arrays a wl_mg handle owns), so `r·iD` of a ghost cell reproduces the stored ghost ϵ (=0).
 #include <cstdint>
 
+#include <cstdlib>
+
 #include "wl_common.hpp"
 
 #ifndef ZT_X
@@ -285,7 +287,11 @@ static int zchunk_for(const GridX& g, int H) {
   const int nt = ztile_count(g.nx, g.ny, H);
   const int np = g.k1 - g.k0;
   int chunks = (1536 + nt - 1) / nt; if (chunks < 1) chunks = 1;
-  int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
+  // small grids are bound by the per-plane latency of the march, not by throughput: shorter chunks (more recomputation, more
+  // workgroups) while the launch would not even fill the 512 workgroup slots of the chip
+  static const int zmin_env = getenv("WL_ZC_MIN") ? atoi(getenv("WL_ZC_MIN")) : 0;
+  const int zmin = zmin_env ? zmin_env : ((long)nt * ((np + 15) / 16) >= 512 ? 16 : ((long)nt * ((np + 7) / 8) >= 512 ? 8 : 4));
+  int zc = (np + chunks - 1) / chunks; if (zc < zmin) zc = zmin; if (zc > np) zc = np;
   return zc;
 }
 // GaussSeidelRB!(it=4,ω): emid and rout are scratch arrays of the level (ghosts zero); on return eps holds the final ϵ,

@@ -350,7 +350,11 @@ int zchunk2(const GridX& g, int HX, int HY) {
   const int np = g.k1 - g.k0;
   static const int target = getenv("WL_PAIR_WGS") ? atoi(getenv("WL_PAIR_WGS")) : 3072;
   int chunks = target >= 0 ? (target + nt - 1) / nt : (-target) / nt; if (chunks < 1) chunks = 1;
-  int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
+  // small grids are bound by the per-plane latency of the march, not by throughput: shorter chunks (more recomputation, more
+  // workgroups) while the launch would not even fill the 512 workgroup slots of the chip
+  static const int zmin_env = getenv("WL_ZC_MIN") ? atoi(getenv("WL_ZC_MIN")) : 0;
+  const int zmin = zmin_env ? zmin_env : ((long)nt * ((np + 15) / 16) >= 512 ? 16 : ((long)nt * ((np + 7) / 8) >= 512 ? 8 : 4));
+  int zc = (np + chunks - 1) / chunks; if (zc < zmin) zc = zmin; if (zc > np) zc = np;
   return zc;
 }
 }  // namespace
