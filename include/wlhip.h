@@ -157,7 +157,12 @@ float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sig
 wl_mg* wl_sim_pois(wl_sim* s);
 int wl_sim_grid(const wl_sim* s, wl_grid* out);
 int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀ BC, (src/Flow.jl:141-145) after the caller filled u */
-/* implementation switches (tests compare the variants): "convz" (z-marching conv_diff!), "fused_smoother" — default 1 */
+/* implementation switches (the tests compare the variants bit for bit).  Defaults in brackets.
+   "fused_smoother"[1] temporally blocked GaussSeidelRB!   "pair"[1] its two-cells-per-thread constant-coefficient variant
+   "constl"[1] constant-coefficient (NoBody) kernels        "fuse_p"[1] fused projection head (div+scale+residual!) and tail
+   "fuse_cfl"[1] CFL folded into the corrector's tail       "tail"[1] smallest V-cycle levels in one launch
+   "store_f"[0] materialise the intermediates f, z          "store_eps"[0] materialise the smoother's final ϵ
+   "overlap"[1] u exchange on a second stream (slabs)       "convz"[0], "convm"[0] alternative conv_diff! kernels (slower) */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
    g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).
