@@ -36,6 +36,26 @@ def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
         assert np.array_equal(sims[tag][1], sims["fast"][1]), tag
 
 
+@pytest.mark.parametrize("dims", [(96, 80, 72), (144, 96, 48), (200, 136, 104), (320, 64, 40)])
+def test_fast_paths_equal_plain_paths_bitwise_on_odd_shapes(w, dims):
+    """non-power-of-two boxes (semi-coarsened hierarchies, tiles and z-chunks that end off the grid): three mom_step! through the
+    default kernels and through the one-kernel-per-pass general kernels — u, p, pois.n, Δt identical."""
+    res = {}
+    rng = np.random.default_rng(7)
+    u0 = np.asfortranarray(rng.uniform(-0.5, 0.5, size=tuple(n + 2 for n in dims) + (3,)).astype(np.float32))
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1, "tail": 0})):
+        s = w.FusedSimulation(dims, (0.3, 0.0, 0.0), dims[0], U=1, nu=0.02, u0=u0)
+        for k, v in opts.items():
+            s.set_option(k, v)
+        for _ in range(3):
+            s.mom_step_()
+        res[tag] = (s.field("u"), s.field("p"), s.pois_n, s.dt)
+        del s
+    assert res["fast"][2] == res["plain"][2] and res["fast"][3] == res["plain"][3]
+    assert np.array_equal(res["fast"][0], res["plain"][0])
+    assert np.array_equal(res["fast"][1], res["plain"][1])
+
+
 def test_benchmark_size_fast_path_equals_plain_path_bitwise(w):
     """512³ — the size bench.py times: one mom_step! through the default kernels (pair smoother with fused prolongation, constant
     coefficients, fused projection head/tails, intermediates not stored) and through the one-kernel-per-pass general kernels."""

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(CZ_X * CZ_Y) k_conv_z(GridX g, float* __restri
         const long oa = (long)a * g.cs + op;
         if (FUSE) {
           const float fn = bd.u0[oa] + bd.dt * acc - 0.f;                       // BDIM! :178 (V ≡ 0)
-          r[oa] = fn;
+          if (r) r[oa] = fn;
           if (in) {
             const float xx = (0.f / 2 + 0.f) + bd.mu0[oa] * fn;                 // :179 (μ₁ ≡ 0, V ≡ 0)
             float un = (bd.pre == 0.f) ? xx : (u[oa] * bd.pre + xx);

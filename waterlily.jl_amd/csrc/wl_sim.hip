@@ -279,7 +279,7 @@ struct wl_sim {
       ProfScope pc(WL_PROF_CONVDIFF, s);
       if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
         WL_TRY(sync_u(s));
-        WL_TRY(wl::conv_diff_z(f, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
+        WL_TRY(wl::conv_diff_z(store_f ? f : nullptr, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
         WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
       } else WL_TRY(conv_fused(u0, u, 0.f, 1.f, s));
     } else {
@@ -296,7 +296,7 @@ struct wl_sim {
       { ProfScope pc(WL_PROF_CONVDIFF, s);
         if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
           WL_TRY(sync_u(s));
-          WL_TRY(wl::conv_diff_z(f, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
+          WL_TRY(wl::conv_diff_z(store_f ? f : nullptr, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
           WL_TRY(wl::conv_q1(sigma, u, G, d.nu, d.perdir_mask, d.scheme, s));
         } else WL_TRY(conv_fused(u, us, 1.f, 0.5f, s)); }
       std::swap(u, us);
