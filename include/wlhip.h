@@ -70,6 +70,11 @@ int wl_L2_inside(const float* a, const wl_grid* g, double* host_out, void* strea
 /* BC!(a,U::tuple,saveexit,perdir): all faces, all components, one launch (edge/corner values equal the
  * reference's sequential (i,j) order).  perdir_mask bit (j-1) set = direction j periodic.            */
 int wl_bc_vec(float* a, const wl_grid* g, const float* host_U, int saveexit, unsigned perdir_mask, void* stream);
+/* Function-valued BCs and body forces that depend on position.  A C ABI cannot call a Julia closure, so the host
+   tabulates it: Ub has the shape of `a` and holds uBC(i,loc(i,I),t) on the two outermost layers of every non-periodic direction
+   (other cells are never read); G holds g(i,loc(i,I),t)+∂ₜuBC for every cell. */
+int wl_bc_vec_fn(float* a, const float* Ub, const wl_grid* g, int saveexit, unsigned perdir_mask, void* stream);  /* BC!(a,uBC::Function,…) src/core.jl:201-219 */
+int wl_accelerate_field(float* r, const float* G, const wl_grid* g, void* stream);                               /* accelerate!(r,t,g,U) src/Flow.jl:69-73 */
 int wl_bc_per_scalar(float* a, const wl_grid* g, unsigned perdir_mask, void* stream);   /* perBC!   src/core.jl:239-243 */
 int wl_exit_bc(float* u, const float* u0, const wl_grid* g, float dt, void* stream);    /* exitBC!  src/core.jl:226-233 */
 

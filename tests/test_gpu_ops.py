@@ -281,3 +281,33 @@ def test_generic_reductions(w):
     assert abs(s.value - a64.sum()) < 1e-6 and abs(l1.value - np.abs(a64).sum()) < 1e-5
     assert linf.value == np.abs(a).max() and mx.value == a.max()
     assert abs(dot.value - a64 @ b64) < 1e-6
+
+
+# ---------------------------------------------------------------- function-valued BCs (host-tabulated)
+# test/test_core.jl (BC! with a non-uniform function) on the HIP path + comparison with the oracle on random fields
+def test_BC_function_nonuniform(w, oracle):
+    import math
+    Ng, D = (8, 8, 8), 3
+    Ubc2 = lambda i, x, t: math.cos(2 * math.pi * x[0] / 8) if i == 1 else (math.sin(2 * math.pi * x[1] / 8) if i == 2 else math.tan(math.pi * x[2] / 16))
+    ug = w.jl_zeros(Ng + (D,))
+    w.BC_(ug, Ubc2)
+    u = w.to_host(ug)
+    pi = math.pi
+    assert np.allclose(u[0, :, :, 0], math.cos(-pi / 4)) and np.allclose(u[1, :, :, 0], 1.0) and np.allclose(u[-1, :, :, 0], math.cos(6 * pi / 4), atol=1e-6)
+    assert np.allclose(u[:, 0, :, 1], math.sin(-pi / 4)) and np.allclose(u[:, 1, :, 1], 0.0, atol=1e-7) and np.allclose(u[:, -1, :, 1], math.sin(6 * pi / 4))
+    assert np.allclose(u[:, :, 0, 2], math.tan(-pi / 16), atol=1e-6) and np.allclose(u[:, :, 1, 2], 0.0, atol=1e-7)
+
+
+@pytest.mark.parametrize("Ng,perdir,saveexit", [((9, 7), (), False), ((8, 6, 7), (), False), ((8, 6, 7), (2,), True), ((10, 8), (1,), False)])
+def test_BC_function_matches_oracle(w, oracle, Ng, perdir, saveexit):
+    """random interior field + a position- and time-dependent uBC: every cell against the oracle's BC!(a,uBC::Function,…).
+    The Neumann update (uBC(I)+a[S])-uBC(S) is evaluated in the reference's order; tolerance 2 ulp of the field scale."""
+    D = len(Ng)
+    rng = np.random.default_rng(71)
+    a0 = np.asfortranarray(rng.uniform(-1, 1, size=Ng + (D,)).astype(np.float32))
+    fn = lambda i, x, t: float(np.float32(0.3 * i + 0.11 * x[0] - 0.07 * x[1] * x[0] + (0.05 * x[2] if D == 3 else 0.0) + 0.2 * t))
+    ao = a0.copy(order="F")
+    oracle.BC(ao, fn, saveexit, perdir, 0.75)
+    ag = w.to_device(a0)
+    w.BC_(ag, fn, saveexit, perdir, 0.75)
+    assert np.abs(w.to_host(ag) - ao).max() <= 5e-7 * max(1.0, float(np.abs(ao).max()))

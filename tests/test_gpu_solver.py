@@ -516,3 +516,39 @@ def test_circle_in_accelerating_flow(w):
     for _ in range(3):
         sim.mom_step_()
     assert all(k <= 2 for k in sim.pois_n)
+
+
+# test/test_flow.jl:134-140 on the HIP path: a parabolic inflow profile uBC(i,x,t) is maintained by the BCs
+def test_boundary_layer_profile(w):
+    L = 32
+    prof = lambda i, x, t: float(np.float32(4.0 * (((x[1] + 0.5) / (2 * L)) - ((x[1] + 0.5) / (2 * L)) ** 2))) if i == 1 else 0.0
+    sim = w.Simulation((L, L), prof, L, nu=0.001, U=1, duBC_dt=lambda i, x, t: 0.0)
+    sim.sim_step_(10)
+    u = w.to_host(sim.flow.u)
+    assert np.allclose(u[0, :, 0], u[-1, :, 0], rtol=float(np.sqrt(np.finfo(np.float32).eps)))
+
+
+# test/test_flow.jl:142-158 on the HIP path (Float32 here): solid-body rotation seen from the rotating frame — Coriolis and
+# centrifugal forces through g(i,x,t), velocity BC through uBC(i,x,t): the pressure stays (nearly) zero
+def test_rotating_reference_frame(w, oracle):
+    import math
+    Lh = 4
+    N, om = 2 * Lh, 1.0 / Lh
+    x0 = (float(Lh), float(Lh))
+
+    def velocity(i, x, t):
+        s, c = math.sin(om * t), math.cos(om * t)
+        y = (om * (x[0] - x0[0]), om * (x[1] - x0[1]))
+        return s * y[0] + c * y[1] if i == 1 else -c * y[0] + s * y[1]
+
+    def dvel(i, x, t):
+        s, c = math.sin(om * t), math.cos(om * t)
+        y = (om * (x[0] - x0[0]), om * (x[1] - x0[1]))
+        return om * (c * y[0] - s * y[1]) if i == 1 else om * (s * y[0] + c * y[1])
+
+    coriolis = lambda i, x, t: 2 * om * velocity(2, x, t) if i == 1 else -2 * om * velocity(1, x, t)
+    centrifugal = lambda i, x, t: om**2 * (x[i - 1] - x0[i - 1])
+    g = lambda i, x, t: coriolis(i, x, t) + centrifugal(i, x, t)
+    sim = w.Simulation((N, N), velocity, N, U=1, g=g, duBC_dt=dvel)
+    sim.sim_step_()
+    assert oracle.L2(w.to_host(sim.flow.p)) < 3e-3

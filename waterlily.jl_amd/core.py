@@ -88,14 +88,59 @@ def loc(i, I, T=np.float32):
     return np.array([T(I[d]) - T(1.5) - T(1 if d == i - 1 else 0) / T(2) for d in range(len(I))], dtype=T)
 
 
+def tabulate_shell(fn, shape, D, t, perdir=()):
+    """uBC(i,loc(i,I),t) on the two outermost layers of every non-periodic direction of a (Ng...,D) array (host side of
+    wl_bc_vec_fn: the closure cannot cross the C ABI, its boundary values can)."""
+    Ng = tuple(shape[:D])
+    tab = np.zeros(Ng + (D,), dtype=np.float32, order="F")
+    done = np.zeros(Ng, dtype=bool)
+    for j in range(D):
+        if (j + 1) in perdir:
+            continue
+        for layer in (0, 1, Ng[j] - 2, Ng[j] - 1):
+            rng = [range(n) for n in Ng]
+            rng[j] = (layer,)
+            for I in np.ndindex(*[len(r) for r in rng]):
+                J = tuple(rng[d][I[d]] for d in range(D))
+                if done[J]:
+                    continue
+                done[J] = True
+                for i in range(1, D + 1):
+                    tab[J + (i - 1,)] = fn(i, loc(i, tuple(k + 1 for k in J)), t)
+    return tab
+
+
 def BC_(a, U, saveexit=False, perdir=(), t=0):
-    """BC!(a,U,saveexit,perdir,t) for a tuple U   src/core.jl:200-219"""
+    """BC!(a,U,saveexit,perdir,t)   src/core.jl:200-219 — U: tuple, or a function uBC(i,x,t) (tabulated on the host)"""
     if callable(U):
-        raise NotImplementedError("Function-valued BCs are outside the HIP hot path this round (SURVEY §8 f3)")
+        D = a.dim() - 1
+        Ub = to_device(tabulate_shell(U, tuple(a.shape), D, t, perdir))
+        g = vgrid(a)
+        check(lib().wl_bc_vec_fn(ptr(a), ptr(Ub), C.byref(g), int(bool(saveexit)), perdir_mask(perdir), stream()))
+        check(lib().wl_stream_sync(stream()))     # Ub is a temporary
+        return
     D = a.dim() - 1
     Uc = (C.c_float * 3)(*([float(v) for v in U] + [0.0] * (3 - D)))
     g = vgrid(a)
     check(lib().wl_bc_vec(ptr(a), C.byref(g), Uc, int(bool(saveexit)), perdir_mask(perdir), stream()))
+
+
+def accelerate_(r, t, g=None, uBC=None, duBC_dt=None):
+    """accelerate!(r,t,g,U)   src/Flow.jl:69-73: r[I,i] += g(i,x,t) + ∂ₜuBC(i,x,t), tabulated on the host (ForwardDiff is the
+    reference's way to get ∂ₜuBC; here the caller supplies it)"""
+    if g is None and not (callable(uBC) and duBC_dt is not None):
+        return
+    D = r.dim() - 1
+    Ng = tuple(r.shape[:D])
+    G = np.zeros(Ng + (D,), dtype=np.float32, order="F")
+    for I in np.ndindex(*Ng):
+        for i in range(1, D + 1):
+            x = loc(i, tuple(k + 1 for k in I))
+            G[I + (i - 1,)] = (g(i, x, t) if g is not None else 0.0) + (duBC_dt(i, x, t) if (callable(uBC) and duBC_dt is not None) else 0.0)
+    Gd = to_device(G)
+    gr = vgrid(r)
+    check(lib().wl_accelerate_field(ptr(r), ptr(Gd), C.byref(gr), stream()))
+    check(lib().wl_stream_sync(stream()))
 
 
 def perBC_(a, perdir):

@@ -201,6 +201,8 @@ bool conv_z_ok(const GridX& g, unsigned per);
 int conv_diff_z(float* f, const float* u_adv, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, int scheme, float dt, float pre, float post, hipStream_t s);
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s);
 int accelerate(float* r, const GridX& g, const float* a, hipStream_t s);
+int bc_vec_fn(float* a, const float* Ub, const GridX& g, int saveexit, unsigned per, hipStream_t s);
+int add_field(float* r, const float* gfield, size_t n, hipStream_t s);
 void conv_march_enable(int on);
 bool conv_march_ok(const GridX& g);
 int conv_march(float* r, const float* u, const GridX& g, float nu, unsigned per, int scheme, int kfirst, int klast, const void* bdim_args, hipStream_t s);

@@ -328,6 +328,57 @@ __global__ void k_bc_vec(GridX g, float* __restrict__ a_, float U0, float U1, fl
     a_[(long)a * g.cs + o] = v;
   }
 }
+// BC!(a,uBC::Function,saveexit,perdir,t) with the boundary values tabulated by the host: Ub has the shape of `a` and holds
+// uBC(i,loc(i,I),t) on the two outermost layers of every non-periodic direction (nothing else is read).  The reference applies the
+// (i,j) face updates sequentially; a Neumann update is  a[I] = (uBC(I) + a[S]) - uBC(S)  with S the inward neighbour, and at edges
+// and corners a[S] may itself be the product of an earlier direction.  The chain is collected from the last direction inwards
+// (as in k_bc_vec) and then evaluated from its innermost cell outwards — the order in which the reference produces the values.
+template <int D>
+__global__ void k_bc_vec_fn(GridX g, float* __restrict__ a_, const float* __restrict__ Ub, int saveexit, unsigned per, int zwalls) {
+  const int pid = blockIdx.y, d = pid / 3, which = pid % 3;
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
+  const int d1 = (d == 0) ? 1 : 0, d2 = (d == 2) ? 1 : 2;
+  const int n1 = (d1 == 0) ? g.nx : g.ny;
+  const long cnt = (long)n1 * ((D == 3) ? ((d2 == 1) ? g.ny : g.nz) : 1);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  int loc[3] = {0, 0, 0};
+  loc[d1] = (int)(q % n1);
+  if (D == 3) loc[d2] = (int)(q / n1);
+  const int Id = (which == 0) ? 1 : (which == 1 ? 2 : N[d]);
+  int I[3];
+  if (d == 2) { const int kl = Id - 1 - g.gk; if (kl < 0 || kl >= g.nz) return; loc[2] = kl; if (!zwalls) return; }
+  else loc[d] = Id - 1;
+  I[0] = loc[0] + 1; I[1] = loc[1] + 1; I[2] = (D == 3) ? g.gk + loc[2] + 1 : 1;
+  if (D == 3 && d != 2) {
+    const int K = I[2];
+    const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || K == 1 || K == N[2];
+    if (!owned) return;
+  }
+  auto off = [&](const int* J) -> long { return (long)(J[0] - 1) + (long)(J[1] - 1) * g.sy + ((D == 3) ? (long)(J[2] - 1 - g.gk) * g.sz : 0); };
+  for (int a = 0; a < D; a++) {
+    if (!bc_touched<D>(I, N, a, saveexit, per)) continue;
+    long chain[4]; bool neu[4]; int nc = 0;        // cells from I inwards; neu[q]: step q→q+1 is a Neumann (function) step, else a periodic copy
+    int J[3] = {I[0], I[1], I[2]};
+    chain[0] = off(J);
+    bool dirichlet = false;
+    for (int b = D - 1; b >= 0; b--) {
+      const bool pb = (per >> b) & 1u;
+      int moved = 0;
+      if (pb) { if (J[b] == 1) { J[b] = N[b] - 1; moved = 1; } else if (J[b] == N[b]) { J[b] = 2; moved = 1; } }
+      else if (a == b) { if (J[b] == 1 || J[b] == 2 || (J[b] == N[b] && !(saveexit && a == 0))) { dirichlet = true; break; } }
+      else { if (J[b] == 1) { J[b] = 2; moved = 2; } else if (J[b] == N[b]) { J[b] = N[b] - 1; moved = 2; } }
+      if (moved) { neu[nc] = moved == 2; nc++; chain[nc] = off(J); }
+    }
+    const float* __restrict__ Ua = Ub + (long)a * g.cs;
+    float v = dirichlet ? Ua[chain[nc]] : a_[(long)a * g.cs + chain[nc]];
+    for (int qk = nc - 1; qk >= 0; qk--) if (neu[qk]) v = (Ua[chain[qk]] + v) - Ua[chain[qk + 1]];
+    a_[(long)a * g.cs + chain[0]] = v;
+  }
+}
+__global__ void k_add_field(float* __restrict__ r, const float* __restrict__ gfield, long n) {
+  for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (long)gridDim.x * WL_BLOCK) r[q] += gfield[q];
+}
 // perBC!(a,perdir) for a scalar   src/core.jl:239-243  (same last-direction-wins resolution)
 template <int D>
 __global__ void k_bc_per_scalar(GridX g, float* __restrict__ a_, unsigned per) {
@@ -410,6 +461,20 @@ int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per,
   const int zwalls = (g.D == 3) ? ((dist && ((per >> 2) & 1u)) ? 0 : 1) : 0;
   dim3 grid((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)(3 * g.D), 1);
   DSEL(g.D, k_bc_vec, grid, dim3(WL_BLOCK), 0, s, g, a, U[0], U[1], g.D == 3 ? U[2] : 0.f, saveexit, per, zwalls);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int bc_vec_fn(float* a, const float* Ub, const GridX& g, int saveexit, unsigned per, hipStream_t s) {
+  long cmax = (long)g.ny * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > (long)g.nx * (g.D == 3 ? g.nz : 1) ? cmax : (long)g.nx * (g.D == 3 ? g.nz : 1);
+  cmax = cmax > g.sz ? cmax : g.sz;
+  const bool dist = (g.D == 3) && (g.nz != g.gnz);
+  const int zwalls = (g.D == 3) ? ((dist && ((per >> 2) & 1u)) ? 0 : 1) : 0;
+  dim3 grid((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)(3 * g.D), 1);
+  DSEL(g.D, k_bc_vec_fn, grid, dim3(WL_BLOCK), 0, s, g, a, Ub, saveexit, per, zwalls);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int add_field(float* r, const float* gf, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(k_add_field, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, r, gf, (long)n);
   WL_LAUNCH_CHECK(); return 0;
 }
 int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s) {

@@ -39,23 +39,27 @@ def CFL(a, dt_max=10):
 class Flow:
     """Flow(N,uBC;Δt,ν,u0,perdir,exitBC,λ)   src/Flow.jl:114-148 — fields live in HBM (float32)."""
 
-    def __init__(self, N, uBC, dt=0.25, nu=0.0, g=None, u0=None, perdir=(), exitBC=False, lam=core.QUICK, T=np.float32):
+    def __init__(self, N, uBC, dt=0.25, nu=0.0, g=None, u0=None, perdir=(), exitBC=False, lam=core.QUICK, T=np.float32, duBC_dt=None):
+        """uBC: tuple or function uBC(i,x,t); g: None or function g(i,x,t); duBC_dt(i,x,t): the time derivative of a function uBC
+        (the reference obtains it with ForwardDiff, src/Flow.jl:72-73).  Functions are tabulated on the host each time they are
+        needed (wl_bc_vec_fn / wl_accelerate_field) — correct for any closure, meant for small problems."""
         if np.dtype(T) != np.float32:
             raise NotImplementedError("the HIP path computes in Float32")
-        if g is not None or callable(uBC):
-            raise NotImplementedError("Function-valued g/uBC are outside the HIP hot path this round (SURVEY §8 f3)")
         D = len(N)
         self.D, self.N = D, tuple(int(n) for n in N)
         Ng = tuple(n + 2 for n in self.N)
         self.Ng = Ng
-        self.uBC = tuple(float(v) for v in uBC)
+        self.uBC = uBC if callable(uBC) else tuple(float(v) for v in uBC)
+        self.duBC_dt = duBC_dt
         self.dt = [np.float32(dt)]
         self.nu = np.float32(nu)
-        self.g = None
+        self.g = g
         self.exitBC = bool(exitBC)
         self.perdir = tuple(perdir)
         self.lam = lam
         # u = Array{T}(undef, Nd...) |> mem; apply!(u0,u)                 :139-140
+        if u0 is None and callable(self.uBC):
+            u0 = lambda i, x: self.uBC(i, x, 0.0)        # Simulation: u0 defaults to uBC at t=0   src/WaterLily.jl:100
         if u0 is None:
             u_host = np.empty(Ng + (D,), dtype=np.float32, order="F")
             for i in range(D):
@@ -87,24 +91,34 @@ class Flow:
         return s
 
 
-def mom_predict_(a):
-    """mom_predict!   src/Flow.jl:190-196"""
+def _times(a):
+    """t₁ = sum(Δt), t₀ = t₁ - Δt[end]   src/Flow.jl:157"""
+    t1 = np.float32(0)
+    for d in a.dt:
+        t1 = np.float32(t1 + d)
+    return np.float32(t1 - a.dt[-1]), t1
+
+
+def mom_predict_(a, t0=0.0, t1=0.0):
+    """mom_predict!(a,t₀,t₁)   src/Flow.jl:190-196"""
     conv_diff_(a.f, a.u0, a.sigma, a.lam, nu=a.nu, perdir=a.perdir)
+    core.accelerate_(a.f, float(t0), a.g, a.uBC, a.duBC_dt)
     BDIM_(a)
-    BC_(a.u, a.uBC, a.exitBC, a.perdir)
+    BC_(a.u, a.uBC, a.exitBC, a.perdir, float(t1))
     if a.exitBC:
         exitBC_(a.u, a.u0, a.dt[-1])
 
 
-def mom_correct_(a):
-    """mom_correct!   src/Flow.jl:205-210"""
+def mom_correct_(a, t=0.0):
+    """mom_correct!(a,t)   src/Flow.jl:205-210"""
     conv_diff_(a.f, a.u, a.sigma, a.lam, nu=a.nu, perdir=a.perdir)
+    core.accelerate_(a.f, float(t), a.g, a.uBC, a.duBC_dt)
     BDIM_(a)
     scale_u_(a, 0.5)
-    BC_(a.u, a.uBC, a.exitBC, a.perdir)
+    BC_(a.u, a.uBC, a.exitBC, a.perdir, float(t))
 
 
-def mom_project_(a, b, w):
+def mom_project_(a, b, w, t=0.0):
     """mom_project!(a,b,w,t)   src/Flow.jl:223-232"""
     dt = np.float32(np.float32(w) * a.dt[-1])
     g = sgrid(b.x)
@@ -114,15 +128,16 @@ def mom_project_(a, b, w):
     b.solver_()
     check(lib().wl_project(ptr(a.u), ptr(b.L), ptr(b.x), C.byref(g), stream()))
     check(lib().wl_div_scalar(ptr(b.x), float(dt), n, stream()))            # b.x ./= dt
-    BC_(a.u, a.uBC, a.exitBC, a.perdir)
+    BC_(a.u, a.uBC, a.exitBC, a.perdir, float(t))
 
 
 def mom_step_(a, b):
     """mom_step!(a::Flow,b::AbstractPoisson)   src/Flow.jl:156-167 — written on the leaf operations, line for line."""
     check(lib().wl_d2d(ptr(a.u0), ptr(a.u), 4 * a.u.numel(), stream()))        # a.u⁰ .= a.u
     scale_u_(a, 0)
-    mom_predict_(a)
-    mom_project_(a, b, 1)
-    mom_correct_(a)
-    mom_project_(a, b, 0.5)
+    t0, t1 = _times(a)
+    mom_predict_(a, t0, t1)
+    mom_project_(a, b, 1, t1)
+    mom_correct_(a, t1)
+    mom_project_(a, b, 0.5, t1)
     a.dt.append(CFL(a))

@@ -15,11 +15,12 @@ class Simulation:
     """Simulation(dims,uBC,L;U,Δt,ν,ϵ,perdir,exitBC,λ,body,T) over leaf operations (reference orchestration)."""
 
     def __init__(self, dims, uBC, L, U=None, dt=0.25, nu=0.0, eps=1, perdir=(), u0=None, exitBC=False, lam=core.QUICK,
-                 body=None, T=np.float32):
+                 body=None, T=np.float32, g=None, duBC_dt=None):
         if U is None:
+            assert not callable(uBC), "`U` (velocity scale) must be specified if boundary conditions `uBC` is a `Function`"   # :99
             U = float(np.sqrt(sum(float(v) ** 2 for v in uBC)))                  # :100
         self.U, self.L, self.eps = float(U), float(L), eps
-        self.flow = Flow(dims, uBC, dt=dt, nu=nu, u0=u0, perdir=perdir, exitBC=exitBC, lam=lam, T=T)   # :103
+        self.flow = Flow(dims, uBC, dt=dt, nu=nu, g=g, u0=u0, perdir=perdir, exitBC=exitBC, lam=lam, T=T, duBC_dt=duBC_dt)   # :103
         self.body = body
         if body is not None:
             raise NotImplementedError("bodies go through FusedSimulation.measure_sphere_ this round")
