@@ -113,6 +113,11 @@ int wl_poisson_solve(float* eps, float* r, float* x, float* z, const float* L, c
                      void* stream);                                                     /* solver!(p::Poisson;tol,itmx) :212-223 */
 size_t wl_reduce_workspace_bytes(void);
 
+/* ---- temporal averages: src/Metrics.jl:200-255 --------------------------------- */
+/* update!(meanflow,flow) with the weight ε computed by the caller (:237-239); UU may be NULL (uu_stats=false) */
+int wl_meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const wl_grid* g, float eps, void* stream);
+int wl_meanflow_uu(float* tau, const float* UU, const float* U, const wl_grid* g, void* stream);   /* uu!(τ,a) :250-252 */
+
 /* ---- multigrid transfer: src/MultiLevelPoisson.jl ---------------------------------------------- */
 int wl_restrict(float* a_coarse, const wl_grid* gc, const float* b_fine, const wl_grid* gf, void* stream);    /* restrict! :49 */
 int wl_prolongate(float* a_fine, const wl_grid* gf, const float* b_coarse, const wl_grid* gc, void* stream);  /* prolongate! :50 */

@@ -552,3 +552,46 @@ def test_rotating_reference_frame(w, oracle):
     sim = w.Simulation((N, N), velocity, N, U=1, g=g, duBC_dt=dvel)
     sim.sim_step_()
     assert oracle.L2(w.to_host(sim.flow.p)) < 3e-3
+
+
+# test/test_metrics.jl:67-90 on the HIP path: temporal averages of a steady boundary-layer flow equal the instantaneous fields
+def test_meanflow_temporal_averages(w, tmp_path):
+    L = 32
+    prof = lambda i, x, t: float(np.float32(4.0 * (((x[1] + 0.5) / (2 * L)) - ((x[1] + 0.5) / (2 * L)) ** 2))) if i == 1 else 0.0
+    sim = w.Simulation((L, L), prof, L, nu=0.001, U=1, duBC_dt=lambda i, x, t: 0.0)
+    mean = w.MeanFlow(sim.flow, uu_stats=True)
+    for t in np.arange(0.0, 4.0 + 1e-9, 0.2):
+        sim.sim_step_(float(t))
+        mean.update_(sim.flow)
+    tol = float(np.sqrt(np.finfo(np.float32).eps))
+    u, p = w.to_host(sim.flow.u), w.to_host(sim.flow.p)
+    U, P, UU = w.to_host(mean.U), w.to_host(mean.P), w.to_host(mean.UU)
+    assert np.allclose(u, U, atol=tol) and np.allclose(p, P, atol=tol)
+    for i in range(2):
+        for j in range(2):
+            assert np.allclose(u[:, :, i] * u[:, :, j], UU[:, :, i, j], atol=tol)
+    tau = w.to_host(mean.uu())
+    for i in range(2):
+        for j in range(2):
+            assert np.allclose(UU[:, :, i, j] - U[:, :, i] * U[:, :, j], tau[:, :, i, j], atol=tol)
+    assert sim.flow.time() == mean.time()
+    # one update step against the formula in float32 (bit for bit)
+    m2 = w.MeanFlow(sim.flow, t_init=0.0, uu_stats=True)
+    m2.P.fill_(0.25); m2.U.fill_(-0.5); m2.UU.fill_(2.0)
+    m2.t = [np.float32(0.0), np.float32(1.0)]
+    dt = np.float32(sim.flow.time() - np.float32(1.0))
+    eps = np.float32(dt / np.float32(dt + np.float32(1.0) + np.finfo(np.float32).eps))
+    m2.update_(sim.flow)
+    one_m = np.float32(1) - eps
+    assert np.array_equal(w.to_host(m2.P), eps * p + one_m * np.float32(0.25))
+    assert np.array_equal(w.to_host(m2.U), eps * u + one_m * np.float32(-0.5))
+    assert np.array_equal(w.to_host(m2.UU)[:, :, 0, 1], eps * (u[:, :, 0] * u[:, :, 1]) + one_m * np.float32(2.0))
+    # checkpoint round trip (the reference's JLD2 extension stores u, p, Δt)
+    path = str(tmp_path / "flow.npz")
+    w.save_checkpoint(path, sim.flow)
+    dt_hist = list(sim.flow.dt)
+    sim.flow.u.zero_(); sim.flow.p.zero_(); sim.flow.dt[:] = [np.float32(0.25)]
+    w.load_checkpoint(path, sim.flow)
+    assert np.array_equal(w.to_host(sim.flow.u), u) and np.array_equal(w.to_host(sim.flow.p), p) and list(sim.flow.dt) == dt_hist
+    mean.reset_()
+    assert float(w.to_host(mean.U).max()) == 0.0 and mean.t == [np.float32(0.0)]

@@ -8,4 +8,5 @@ from .core import (BC_, CDS, QUICK, VANLEER, L2, exitBC_, inside, jl_zeros, loc,
 from .flow import BDIM_, CFL, Flow, conv_diff_, mom_correct_, mom_predict_, mom_project_, mom_step_, scale_u_  # noqa: F401
 from .poisson import (pcg_, poisson_solver_, GaussSeidelRB_, Jacobi_, L1, Linf, MultiLevelPoisson, Poisson, increment_, mult_, norms, prolongate_,  # noqa: F401
                       residual_, restrict_, restrictL_, set_diag_, smooth_, update_)
+from .metrics import MeanFlow, load_checkpoint, save_checkpoint  # noqa: F401
 from .simulation import FusedSimulation, Simulation  # noqa: F401

@@ -47,6 +47,8 @@ SIGNATURES = {
     "wl_bc_per_scalar": (i32, [P, G, u32, P]),
     "wl_bc_vec_fn": (i32, [P, P, G, i32, u32, P]),
     "wl_accelerate_field": (i32, [P, P, G, P]),
+    "wl_meanflow_update": (i32, [P, P, P, P, P, G, f32, P]),
+    "wl_meanflow_uu": (i32, [P, P, P, G, P]),
     "wl_exit_bc": (i32, [P, P, G, f32, P]),
     "wl_conv_diff": (i32, [P, P, P, G, f32, u32, i32, P]),
     "wl_bdim": (i32, [P, P, P, P, P, P, G, f32, f32, f32, P]),

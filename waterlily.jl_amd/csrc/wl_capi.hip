@@ -348,6 +348,8 @@ int wl_dot(const float* a, const float* b, size_t n, double* out, void* st) { DE
 
 int wl_bc_vec(float* a, const wl_grid* g, const float* U, int saveexit, unsigned per, void* st) { GRID_ARG(g); return wl::bc_vec(a, G, U, saveexit, per, wl_stream(st)); }
 int wl_bc_vec_fn(float* a, const float* Ub, const wl_grid* g, int saveexit, unsigned per, void* st) { GRID_ARG(g); WL_CHECK(a && Ub && a != Ub, "bad argument"); return wl::bc_vec_fn(a, Ub, G, saveexit, per, wl_stream(st)); }
+int wl_meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const wl_grid* g, float eps, void* st) { GRID_ARG(g); WL_CHECK(P && U && p && u, "bad argument"); return wl::meanflow_update(P, U, UU, p, u, G, eps, wl_stream(st)); }
+int wl_meanflow_uu(float* tau, const float* UU, const float* U, const wl_grid* g, void* st) { GRID_ARG(g); WL_CHECK(tau && UU && U, "bad argument"); return wl::meanflow_uu(tau, UU, U, G, wl_stream(st)); }
 int wl_accelerate_field(float* r, const float* gfield, const wl_grid* g, void* st) { GRID_ARG(g); WL_CHECK(r && gfield, "bad argument"); return wl::add_field(r, gfield, (size_t)G.cs * (size_t)G.D, wl_stream(st)); }
 int wl_bc_per_scalar(float* a, const wl_grid* g, unsigned per, void* st) { GRID_ARG(g); return wl::bc_per_scalar(a, G, per, wl_stream(st)); }
 int wl_conv_diff(float* r, const float* u, float* Phi, const wl_grid* g, float nu, unsigned per, int scheme, void* st) { GRID_ARG(g); return wl::conv_diff(r, u, Phi, G, nu, per, scheme, wl_stream(st)); }

@@ -203,6 +203,8 @@ int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, 
 int accelerate(float* r, const GridX& g, const float* a, hipStream_t s);
 int bc_vec_fn(float* a, const float* Ub, const GridX& g, int saveexit, unsigned per, hipStream_t s);
 int add_field(float* r, const float* gfield, size_t n, hipStream_t s);
+int meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const GridX& g, float e, hipStream_t s);
+int meanflow_uu(float* tau, const float* UU, const float* U, const GridX& g, hipStream_t s);
 void conv_march_enable(int on);
 bool conv_march_ok(const GridX& g);
 int conv_march(float* r, const float* u, const GridX& g, float nu, unsigned per, int scheme, int kfirst, int klast, const void* bdim_args, hipStream_t s);

@@ -376,6 +376,21 @@ __global__ void k_bc_vec_fn(GridX g, float* __restrict__ a_, const float* __rest
     a_[(long)a * g.cs + chain[0]] = v;
   }
 }
+// MeanFlow update!  src/Metrics.jl:236-248:  P = ε·p + (1−ε)·P ;  U = ε·u + (1−ε)·U ;  UU[I,i,j] = ε·(u[I,i]·u[I,j]) + (1−ε)·UU[I,i,j]  (all cells)
+__global__ void k_meanflow(float* __restrict__ P, float* __restrict__ U, float* __restrict__ UU, const float* __restrict__ p, const float* __restrict__ u, long cs, int D, float e) {
+  const float one_m = 1 - e;
+  for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < cs; q += (long)gridDim.x * WL_BLOCK) {
+    P[q] = e * p[q] + one_m * P[q];
+    float uv[3];
+    for (int i = 0; i < D; i++) { uv[i] = u[(long)i * cs + q]; U[(long)i * cs + q] = e * uv[i] + one_m * U[(long)i * cs + q]; }
+    if (UU) for (int j = 0; j < D; j++) for (int i = 0; i < D; i++) { const long o = (long)(i + j * D) * cs + q; UU[o] = e * (uv[i] * uv[j]) + one_m * UU[o]; }
+  }
+}
+// uu!(τ,a)  :250-252:  τ[I,i,j] = UU[I,i,j] − U[I,i]·U[I,j]
+__global__ void k_meanflow_uu(float* __restrict__ tau, const float* __restrict__ UU, const float* __restrict__ U, long cs, int D) {
+  for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < cs; q += (long)gridDim.x * WL_BLOCK)
+    for (int j = 0; j < D; j++) for (int i = 0; i < D; i++) { const long o = (long)(i + j * D) * cs + q; tau[o] = UU[o] - U[(long)i * cs + q] * U[(long)j * cs + q]; }
+}
 __global__ void k_add_field(float* __restrict__ r, const float* __restrict__ gfield, long n) {
   for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (long)gridDim.x * WL_BLOCK) r[q] += gfield[q];
 }
@@ -471,6 +486,14 @@ int bc_vec_fn(float* a, const float* Ub, const GridX& g, int saveexit, unsigned 
   const int zwalls = (g.D == 3) ? ((dist && ((per >> 2) & 1u)) ? 0 : 1) : 0;
   dim3 grid((unsigned)((cmax + WL_BLOCK - 1) / WL_BLOCK), (unsigned)(3 * g.D), 1);
   DSEL(g.D, k_bc_vec_fn, grid, dim3(WL_BLOCK), 0, s, g, a, Ub, saveexit, per, zwalls);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const GridX& g, float e, hipStream_t s) {
+  hipLaunchKernelGGL(k_meanflow, dim3(grid1d((size_t)g.cs)), dim3(WL_BLOCK), 0, s, P, U, UU, p, u, g.cs, g.D, e);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int meanflow_uu(float* tau, const float* UU, const float* U, const GridX& g, hipStream_t s) {
+  hipLaunchKernelGGL(k_meanflow_uu, dim3(grid1d((size_t)g.cs)), dim3(WL_BLOCK), 0, s, tau, UU, U, g.cs, g.D);
   WL_LAUNCH_CHECK(); return 0;
 }
 int add_field(float* r, const float* gf, size_t n, hipStream_t s) {
