@@ -313,14 +313,15 @@ struct wl_sim {
     const float dtl = w * dt.back();
     cfl_done = false;
     WL_TRY(sync_u(s));                                                                     // div(u) reads the halo planes
-    if (ps && use_fuse_p && !d.perdir_mask) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
+    if (ps && use_fuse_p && !(comm && d.perdir_mask)) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
+      WL_TRY(wl::bc_per_scalar(p, G, d.perdir_mask, s));                                   // residual!: perBC!(x) :93 (copies commute with the scaling)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
       { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s)); }
       std::swap(p, ps); l0.x = p;
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
-      if (with_cfl && use_fuse_cfl && us && !d.exitBC) {   // + flux_out and its maximum; projected u lands in the spare array
+      if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
         WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s));
         WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
         std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
