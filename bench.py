@@ -173,7 +173,7 @@ def main():
         return slab.bench_main(args, world, rank, local_rank, read_prof=read_prof, build_roofline=build_roofline)
 
     sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
-    for opt in ("convz", "fused_smoother", "fuse_p", "constl", "pair", "convm", "fuse_cfl", "store_f", "tail"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
+    for opt in ("convz", "fused_smoother", "fuse_p", "constl", "pair", "convm", "fuse_cfl", "store_f", "tail", "jacobi_march"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
         if os.environ.get("WL_OPT_" + opt) is not None:
             sim.set_option(opt, int(os.environ["WL_OPT_" + opt]))
     for _ in range(args.warmup):

@@ -206,6 +206,7 @@ int add_field(float* r, const float* gfield, size_t n, hipStream_t s);
 int meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const GridX& g, float e, hipStream_t s);
 int meanflow_uu(float* tau, const float* UU, const float* U, const GridX& g, hipStream_t s);
 void conv_march_enable(int on);
+void jacobi_march_enable(int on);
 bool conv_march_ok(const GridX& g);
 int conv_march(float* r, const float* u, const GridX& g, float nu, unsigned per, int scheme, int kfirst, int klast, const void* bdim_args, hipStream_t s);
 int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s);

@@ -415,6 +415,49 @@ __global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* _
   rout[o] = r[o] - w * s;
   x[o] = x[o] + w * e0;
 }
+// The same Jacobi! as a z-march (3-D): a thread walks a chunk of planes of one interior column.  Everything that depends on (i,j)
+// only — the in-plane coefficients and, for each of the three z-classes of a plane (0/1/2 open z-faces), D and iD of the cell
+// and iD of its four in-plane neighbours — is looked up once; r[k±1] come from a register window.  ≈4× fewer instructions per
+// cell than the plane kernel, which was instruction-bound (≈200 VALU instructions for 16 B/cell).
+__global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl, int zchunk) {
+  __shared__ float sDt[27], siDt[27];
+  if (threadIdx.x < 27) { sDt[threadIdx.x] = cl.Dt[threadIdx.x]; siDt[threadIdx.x] = cl.iDt[threadIdx.x]; }
+  __syncthreads();
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  const int ks = g.k0 + pz * zchunk, ke = (ks + zchunk < g.k1) ? ks + zchunk : g.k1;
+  if (ks >= ke) return;
+  const int I0 = i + 1, I1 = j + 1;
+  const int cx0 = wl::wl_cl_cnt(I0, g.nx), cxm = wl::wl_cl_cnt(I0 - 1, g.nx), cxp = wl::wl_cl_cnt(I0 + 1, g.nx);
+  const int cy0 = wl::wl_cl_cnt(I1, g.ny), cym = wl::wl_cl_cnt(I1 - 1, g.ny), cyp = wl::wl_cl_cnt(I1 + 1, g.ny);
+  const float lx = wl::wl_cl_coef(I0, g.nx, cl.c[0]), lxp = wl::wl_cl_coef(I0 + 1, g.nx, cl.c[0]);
+  const float ly = wl::wl_cl_coef(I1, g.ny, cl.c[1]), lyp = wl::wl_cl_coef(I1 + 1, g.ny, cl.c[1]);
+  float d0[3], id0[3], idxm[3], idxp[3], idym[3], idyp[3];     // by z-class of the plane
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    d0[c] = sDt[cx0 + 3 * cy0 + 9 * c]; id0[c] = siDt[cx0 + 3 * cy0 + 9 * c];
+    idxm[c] = siDt[cxm + 3 * cy0 + 9 * c]; idxp[c] = siDt[cxp + 3 * cy0 + 9 * c];
+    idym[c] = siDt[cx0 + 3 * cym + 9 * c]; idyp[c] = siDt[cx0 + 3 * cyp + 9 * c];
+  }
+  auto pick = [](const float* t, int c) -> float { return c == 2 ? t[2] : (c == 1 ? t[1] : t[0]); };
+  long o = m + (long)ks * g.sz;
+  float rm = r[o - g.sz], r0 = r[o];
+  for (int k = ks; k < ke; k++, o += g.sz) {
+    const float rp = r[o + g.sz];
+    const int I2 = g.gk + k + 1;
+    const int cz0 = wl::wl_cl_cnt(I2, g.gnz), czm = wl::wl_cl_cnt(I2 - 1, g.gnz), czp = wl::wl_cl_cnt(I2 + 1, g.gnz);   // uniform
+    const float lz = wl::wl_cl_coef(I2, g.gnz, cl.c[2]), lzp = wl::wl_cl_coef(I2 + 1, g.gnz, cl.c[2]);
+    const float e0 = r0 * pick(id0, cz0);
+    float s = e0 * pick(d0, cz0);
+    s += ((r[o - 1] * pick(idxm, cz0)) * lx + (r[o + 1] * pick(idxp, cz0)) * lxp);
+    s += ((r[o - g.sy] * pick(idym, cz0)) * ly + (r[o + g.sy] * pick(idyp, cz0)) * lyp);
+    s += ((rm * pick(id0, czm)) * lz + (rp * pick(id0, czp)) * lzp);
+    rout[o] = r0 - w * s;
+    x[o] = x[o] + w * e0;
+    rm = r0; r0 = rp;
+  }
+}
 template <int D>
 __global__ void k_jacobi_pp(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, const float* __restrict__ L,
                             const float* __restrict__ Dg, const float* __restrict__ iD, float w) {
@@ -738,8 +781,13 @@ int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, 
   DSEL(g.D, k_gs_init_sweep1, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, eps, r, L, iD);
   WL_LAUNCH_CHECK(); return 0;
 }
+static int g_jacobi_march = 1;
+void jacobi_march_enable(int on) { g_jacobi_march = on; }
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s) {
-  if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
+  if (cl.on && g.D == 3 && g_jacobi_march) {
+    const int zc = wl_march_chunk(g, g.k1 - g.k0);
+    hipLaunchKernelGGL(k_jacobi_march_cl, wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc)), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc);
+  } else if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
   else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
   WL_LAUNCH_CHECK(); return 0;
 }

@@ -486,6 +486,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "store_f") { s->store_f = value != 0; return 0; }
   if (n == "overlap") { WL_TRY(s->sync_u(0)); s->use_overlap = value != 0; return 0; }
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
+  if (n == "jacobi_march") { wl::jacobi_march_enable(value); return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
