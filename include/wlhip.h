@@ -193,6 +193,7 @@ int wl_sim_apply_ic(wl_sim* s, int kind, void* stream);
 int wl_sim_measure_sphere(wl_sim* s, const float* host_center, float R, float eps, void* stream);
 /* pressure_force(sim) for that sphere (src/Metrics.jl:116-133): Float64 accumulation, does not touch flow.f */
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* host_center, float R, double* host_out, void* stream);
+int wl_sim_viscous_force_sphere(wl_sim* s, const float* center, float R, double* out, void* stream);   /* viscous_force(sim) src/Metrics.jl:140-154 (single domain) */
 
 /* ---- multi-GPU: z-slab decomposition, one process per GPU (NEW — the reference has no multi-device path,
  * /root/reference/README.md:153-155).  A wl_comm carries the two primitives the slab path needs, stream-ordered:

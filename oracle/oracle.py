@@ -99,6 +99,8 @@ def lib(omp=False):
         ("wlo_sim_level_dims", None, [C.c_void_p, C.c_int, C.c_void_p]),
         ("wlo_sim_level_field", C.c_void_p, [C.c_void_p, C.c_int, C.c_char_p]),
         ("wlo_sim_pressure_force", None, [C.c_void_p, C.c_void_p]),
+        ("wlo_sim_viscous_force", None, [C.c_void_p, C.c_void_p]),
+        ("wlo_viscous_force", None, [C.c_int, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p, C.c_void_p, dbl, C.c_void_p]),
         ("wlo_sim_pois_norm", dbl, [C.c_void_p, C.c_int]),
         ("wlo_sim_phase", None, [C.c_void_p, C.c_int]),
     ]:
@@ -294,6 +296,14 @@ def L2(a):
 def pressure_force(p, df, center, R):
     out = (C.c_double * p.ndim)()
     lib().wlo_pressure_force(_dt(p), p.ndim, _ptr(p), _ptr(df), _ints(p.shape), _dbls(center), float(R), out)
+    return np.array(list(out))
+
+
+def viscous_force(u, nu, df, center, R):
+    """viscous_force(u,ν,df,body) for a sphere/circle   src/Metrics.jl:148-154"""
+    D = u.ndim - 1
+    out = (C.c_double * D)()
+    lib().wlo_viscous_force(_dt(u), D, _ptr(u), float(nu), _ptr(df), _ints(u.shape[:D]), _dbls(center), float(R), out)
     return np.array(list(out))
 
 
@@ -501,6 +511,15 @@ class Simulation:
         out = (C.c_double * self.D)()
         self._lib.wlo_sim_pressure_force(self.h, out)
         return np.array(list(out))
+
+    def viscous_force(self):
+        out = (C.c_double * self.D)()
+        self._lib.wlo_sim_viscous_force(self.h, out)
+        return np.array(list(out))
+
+    def total_force(self):
+        """total_force(sim) = pressure_force + viscous_force   src/Metrics.jl:156-161"""
+        return self.pressure_force() + self.viscous_force()
 
     def pois_norm(self, which):
         return self._lib.wlo_sim_pois_norm(self.h, {"L1": 0, "Linf": 1, "L2": 2}[which])

@@ -786,6 +786,30 @@ void pressure_force(const S<T, D>& p, const V<T, D>& df, const Body<T, D>& body,
   for (int i = 1; i <= D; i++) { double s = 0; S<T, D> c = df.comp(i); for (long k = 0; k < c.len(); k++) s += (double)c.p[k]; out[i - 1] = s; }
 }
 
+// ∂(i,j,I,u) = ∂uᵢ/∂xⱼ at the centre of cell I                                     src/Metrics.jl:42-44
+template <class T, int D> inline T dudx(int i, int j, const CI<D>& I, const V<T, D>& u) {
+  if (i == j) return u(I + delta<D>(i), i) - u(I, i);                                              // ∂(i,I,u) src/Flow.jl:2
+  const CI<D> Ip = I + delta<D>(j), Im = I - delta<D>(j);
+  return (u(Ip, i) + u(Ip + delta<D>(i), i) - u(Im, i) - u(Im + delta<D>(i), i)) / 4;
+}
+// viscous_force(u,ν,df,body,t):  df[I,:] = -2ν·S(I,u)·nds(body,loc(0,I),t) over the inside cells, summed in Float64     src/Metrics.jl:140-154
+template <class T, int D>
+void viscous_force(const V<T, D>& u, T nu, const V<T, D>& df, const Body<T, D>& body, double* out) {
+  std::fill(df.p, df.p + df.len(), (T)0);
+  for_box<D>(inside<D>(df.n), [&](const CI<D>& I) {
+    T x[D]; loc<T, D>(0, I, x);
+    T d, nrm[D], Vv[D]; body.measure(x, (T)1, d, nrm, Vv);
+    const T k = kern<T>(std::min(std::max(d, (T)-1), (T)1));
+    T nds[D]; for (int j = 0; j < D; j++) nds[j] = nrm[j] * k;
+    for (int i = 1; i <= D; i++) {
+      T acc = 0;
+      for (int j = 1; j <= D; j++) { const T Sij = (dudx<T, D>(i, j, I, u) + dudx<T, D>(j, i, I, u)) / 2; acc += ((-2 * nu) * Sij) * nds[j - 1]; }
+      df(I, i) = acc;
+    }
+  });
+  for (int i = 1; i <= D; i++) { double s = 0; S<T, D> c = df.comp(i); for (long k = 0; k < c.len(); k++) s += (double)c.p[k]; out[i - 1] = s; }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Simulation                                                                src/WaterLily.jl:86-149
 // ----------------------------------------------------------------------------------------------

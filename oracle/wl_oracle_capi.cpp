@@ -138,6 +138,10 @@ double wlo_L2_inside(int dtype, int D, void* a, const int* dims) { double o = 0;
 void wlo_pressure_force(int dtype, int D, void* p, void* df, const int* dims, const double* c, double R, double* out) {
   DISPATCH(dtype, D, { Body<T, DD> b; b.kind = 1; for (int d = 0; d < DD; d++) b.c[d] = (T)c[d]; b.R = (T)R; pressure_force<T, DD>(mkS<T, DD>(p, dims), mkV<T, DD>(df, dims), b, out); });
 }
+// viscous_force(u,ν,df,body)   body = sphere(c,R)
+void wlo_viscous_force(int dtype, int D, void* u, double nu, void* df, const int* dims, const double* c, double R, double* out) {
+  DISPATCH(dtype, D, { Body<T, DD> b; b.kind = 1; for (int d = 0; d < DD; d++) b.c[d] = (T)c[d]; b.R = (T)R; viscous_force<T, DD>(mkV<T, DD>(u, dims), (T)nu, mkV<T, DD>(df, dims), b, out); });
+}
 
 // ---- Poisson / MultiLevelPoisson handle (x,L,z alias the caller's arrays) ---------------------
 void* wlo_pois_create(int dtype, int D, void* x, void* L, void* z, const int* dims, unsigned perdir, int multilevel) {
@@ -269,6 +273,7 @@ void* wlo_sim_level_field(void* h, int l, const char* name) {
   return out;
 }
 void wlo_sim_pressure_force(void* h, double* out) { SIM(h, (pressure_force<T, DD>(sim->flow.p, sim->flow.f, sim->body, out))); }
+void wlo_sim_viscous_force(void* h, double* out) { SIM(h, (viscous_force<T, DD>(sim->flow.u, sim->flow.nu, sim->flow.f, sim->body, out))); }
 double wlo_sim_pois_norm(void* h, int which) { double o = 0; SIM(h, { auto* P = sim->pois.levels[0]; o = which == 0 ? (double)P->L1() : (which == 1 ? (double)P->Linf() : (double)P->L2()); }); return o; }
 // sub-phases of mom_step! for per-phase parity checks: 0 u⁰.=u;scale_u!(0)  1 mom_predict!  2 mom_project!(w=1)  3 mom_correct!  4 mom_project!(w=.5)  5 push!(Δt,CFL)
 void wlo_sim_phase(void* h, int phase) {

@@ -224,6 +224,9 @@ def test_sphere_measure_steps_and_force(w, oracle):
         assert np.abs(sg.field("u") - so.u).max() < 5e-5
     fo, fg = so.pressure_force(), sg.pressure_force_sphere(c, R)
     assert np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+    vo, vg = so.viscous_force(), sg.viscous_force_sphere(c, R)              # src/Metrics.jl:140-154 (row f2)
+    assert np.abs(vo).max() > 0 and np.allclose(vg, vo, rtol=2e-3, atol=2e-3 * np.abs(vo).max())
+    assert np.allclose(sg.total_force_sphere(c, R), so.total_force(), rtol=2e-3, atol=2e-3 * np.abs(fo).max())
 
 
 @pytest.mark.parametrize("N", [(66, 34, 18), (130, 130, 34), (34, 18, 130), (70, 45, 35), (514, 66, 20)])

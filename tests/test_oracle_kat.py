@@ -315,3 +315,19 @@ def test_sim_time_stop_rule(oracle):
     dts = sim.dt
     assert sum(dts[:-2]) * sim.U / sim.L < 1.0 <= sum(dts[:-1]) * sim.U / sim.L
     assert len(sim.pois_n) == 2 * (len(dts) - 1)
+
+
+# ------------------------------------------------------------------ test/test_metrics.jl:54-57 viscous force of a fluid at rest is zero
+def test_viscous_force_zero_and_symmetry(oracle):
+    N = 32
+    for D in (2, 3):
+        shape = (N,) * D
+        c = (N / 2,) * D
+        u = F(shape + (D,), np.float32)
+        df = F(shape + (D,), np.float32)
+        assert np.all(oracle.viscous_force(u, 1.0, df, c, N / 4) == 0)
+        # pure shear u_x = y: S = [[0,1/2],[1/2,0]] — the force on a closed surface vanishes to the discrete symmetry of nds
+        ax = np.arange(N, dtype=np.float32)
+        u[..., 0] = ax.reshape((1, N) + (1,) * (D - 2))
+        f = oracle.viscous_force(u, 1.0, df, c, N / 4)
+        assert np.abs(f).max() < 1e-3 * (N / 4) ** (D - 1)

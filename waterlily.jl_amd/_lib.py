@@ -114,6 +114,8 @@ SIGNATURES = {
     "wl_prof_enable": (i32, [i32]),
     "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),
     "wl_sim_pressure_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),
+
+    "wl_sim_viscous_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),
 }
 
 _lib = None

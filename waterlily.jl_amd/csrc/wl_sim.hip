@@ -118,6 +118,37 @@ __global__ void k_pforce_sphere(GridX g, const float* __restrict__ p, float c0, 
   const long b = blockIdx.x, nb = gridDim.x;
   for (int a = 0; a < 3; a++) { const double v = block_sum(acc[a]); if (threadIdx.x == 0) part[a * nb + b] = v; __syncthreads(); }
 }
+// viscous_force: Σ_inside −2ν·S(I,u)·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:140-154, ∂(i,j,I,u) :42-44
+template <int D>
+__global__ void k_vforce_sphere(GridX g, const float* __restrict__ u, float nu, float c0, float c1, float c2, float R, double* __restrict__ part) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  double acc[3] = {0, 0, 0};
+  const float c[3] = {c0, c1, c2};
+  const long st[3] = {1, g.sy, g.sz};
+  const int nsl = wl_nslots(g);
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    for (int k = g.k0 + pz; k < g.k1; k += nsl) {
+      const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
+      float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
+      float d, n[3]; sphere_measure<D>(x, c, R, 1.f, d, n);
+      const float kk = kern_(fminf(fmaxf(d, -1.f), 1.f));
+      const long o = m + (long)k * g.sz;
+      auto du = [&](int a, int b) -> float {       // ∂u_a/∂x_b at the cell centre
+        const float* __restrict__ f = u + (long)a * g.cs;
+        if (a == b) return f[o + st[a]] - f[o];
+        return (f[o + st[b]] + f[o + st[b] + st[a]] - f[o - st[b]] - f[o - st[b] + st[a]]) / 4;
+      };
+      for (int a = 0; a < D; a++) {
+        float v = 0.f;
+        for (int b = 0; b < D; b++) { const float Sab = (du(a, b) + du(b, a)) / 2; v += ((-2 * nu) * Sab) * (n[b] * kk); }
+        acc[a] += (double)v;
+      }
+    }
+  }
+  const long b = blockIdx.x, nb = gridDim.x;
+  for (int a = 0; a < 3; a++) { const double v = block_sum(acc[a]); if (threadIdx.x == 0) part[a * nb + b] = v; __syncthreads(); }
+}
 __global__ void k_fin3(const double* __restrict__ part, int nb, double* __restrict__ out) {
   for (int a = 0; a < 3; a++) {
     double s = 0.0; for (int q = threadIdx.x; q < nb; q += WL_BLOCK) s += part[(long)a * nb + q];
@@ -548,6 +579,19 @@ int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out
   dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
   // partials need 3*grid.x doubles (<= 3*WL_REDPART): pa and pb are contiguous (2*WL_MAXPART doubles)
   DSEL(D, k_pforce_sphere, grid, dim3(WL_BLOCK), 0, q, G, (const float*)s->p, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
+  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)grid.x, s->mg->ws.res_d + 4);
+  WL_LAUNCH_CHECK();
+  WlCtx& cx = wl_ctx();
+  WL_HIP(hipMemcpyAsync(cx.h_d, s->mg->ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
+  WL_HIP(hipStreamSynchronize(q));
+  for (int a = 0; a < D; a++) out[a] = cx.h_d[a];
+  return 0;
+}
+int wl_sim_viscous_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {
+  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
+  WL_CHECK(!s->comm, "viscous_force on slabs is not built");
+  dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
+  DSEL(D, k_vforce_sphere, grid, dim3(WL_BLOCK), 0, q, G, (const float*)s->u, s->d.nu, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
   hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)grid.x, s->mg->ws.res_d + 4);
   WL_LAUNCH_CHECK();
   WlCtx& cx = wl_ctx();

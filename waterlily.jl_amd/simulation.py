@@ -203,5 +203,16 @@ class FusedSimulation:
         check(lib().wl_sim_pressure_force_sphere(self._h, c, float(R), out, stream()))
         return np.array(out[: self.D])
 
+    def viscous_force_sphere(self, center, R):
+        """viscous_force(sim) for the sphere/circle   src/Metrics.jl:148-154"""
+        c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
+        out = (C.c_double * 3)()
+        check(lib().wl_sim_viscous_force_sphere(self._h, c, float(R), out, stream()))
+        return np.array(out[: self.D])
+
+    def total_force_sphere(self, center, R):
+        """total_force(sim) = pressure_force + viscous_force   src/Metrics.jl:156-161"""
+        return self.pressure_force_sphere(center, R) + self.viscous_force_sphere(center, R)
+
     def sync(self):
         check(lib().wl_stream_sync(stream()))
