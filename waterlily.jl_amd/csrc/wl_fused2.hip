@@ -348,14 +348,35 @@ int g_pro_fast = 1;   // bit 1 of gsrb_pair_enable: register-window prolongation
 int zchunk2(const GridX& g, int HX, int HY) {
   const int nt = ptile_count(g.nx, g.ny, HX, HY);
   const int np = g.k1 - g.k0;
-  static const int target = getenv("WL_PAIR_WGS") ? atoi(getenv("WL_PAIR_WGS")) : 3072;
-  int chunks = target >= 0 ? (target + nt - 1) / nt : (-target) / nt; if (chunks < 1) chunks = 1;
-  // small grids are bound by the per-plane latency of the march, not by throughput: shorter chunks (more recomputation, more
-  // workgroups) while the launch would not even fill the 512 workgroup slots of the chip
+  static const int target = getenv("WL_PAIR_WGS") ? atoi(getenv("WL_PAIR_WGS")) : 0;
   static const int zmin_env = getenv("WL_ZC_MIN") ? atoi(getenv("WL_ZC_MIN")) : 0;
-  const int zmin = zmin_env ? zmin_env : ((long)nt * ((np + 15) / 16) >= 512 ? 16 : ((long)nt * ((np + 7) / 8) >= 512 ? 8 : 4));
-  int zc = (np + chunks - 1) / chunks; if (zc < zmin) zc = zmin; if (zc > np) zc = np;
-  return zc;
+  if (target) {   // experiments: fixed workgroup target
+    int chunks = target >= 0 ? (target + nt - 1) / nt : (-target) / nt; if (chunks < 1) chunks = 1;
+    int zc = (np + chunks - 1) / chunks; const int zmin = zmin_env ? zmin_env : 4; if (zc < zmin) zc = zmin; if (zc > np) zc = np;
+    return zc;
+  }
+  // Few rounds: equal workgroups run in rounds of 512 (256 CUs × 2 resident workgroups of 1024 threads): choose the chunk length that minimises
+  //   rounds × (planes per chunk + pipeline warm-up + start-up),
+  // i.e. trade the warm-up recomputation of short chunks against the idle tail of a partly filled last round.  Grids that cannot fill
+  // one round are bound by the per-plane latency of the march: shortest chunks (>= 4 planes).
+  if ((long)nt * ((np + 31) / 32) >= 2048) {   // many rounds: bandwidth-bound and self-balancing — ≈3072 workgroups measured best at 512³
+    const int chunks = (3072 + nt - 1) / nt;
+    int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
+    return zc;
+  }
+  const int warm = (HY == 3 ? 5 : 3) + 3;
+  long best = -1; int best_zc = np;
+  for (int chunks = 1; chunks <= np; chunks++) {
+    const int zc = (np + chunks - 1) / chunks;
+    if (zc < (zmin_env ? zmin_env : 4)) break;
+    const int nch = (np + zc - 1) / zc;
+    const long W = (long)nt * nch;
+    const long rounds = (W + 511) / 512;
+    long cost = rounds * (zc + warm);
+    if (W < 512) cost = (long)((zc + warm) * 1.25);          // a partly filled chip still pays the full per-plane latency (and unbalanced CUs)
+    if (best < 0 || cost < best) { best = cost; best_zc = zc; }
+  }
+  return best_zc;
 }
 }  // namespace
 
