@@ -283,16 +283,27 @@ bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist) {
   return g.D == 3 && per == 0 && !dist && g.nz == g.gnz && g.nx >= 34 && g.ny >= 18 && (g.k1 - g.k0) >= 8;
 }
 static int zchunk_for(const GridX& g, int H) {
-  // enough workgroups to fill 256 CUs a few times over, but long marches (the pipeline warm-up costs 2H planes per chunk)
   const int nt = ztile_count(g.nx, g.ny, H);
   const int np = g.k1 - g.k0;
-  int chunks = (1536 + nt - 1) / nt; if (chunks < 1) chunks = 1;
-  // small grids are bound by the per-plane latency of the march, not by throughput: shorter chunks (more recomputation, more
-  // workgroups) while the launch would not even fill the 512 workgroup slots of the chip
   static const int zmin_env = getenv("WL_ZC_MIN") ? atoi(getenv("WL_ZC_MIN")) : 0;
-  const int zmin = zmin_env ? zmin_env : ((long)nt * ((np + 15) / 16) >= 512 ? 16 : ((long)nt * ((np + 7) / 8) >= 512 ? 8 : 4));
-  int zc = (np + chunks - 1) / chunks; if (zc < zmin) zc = zmin; if (zc > np) zc = np;
-  return zc;
+  if ((long)nt * ((np + 31) / 32) >= 2048) {   // many rounds of workgroups: long marches (the pipeline warm-up costs 2H-1 planes per chunk)
+    const int chunks = (1536 + nt - 1) / nt;
+    int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;
+    return zc;
+  }
+  // few rounds (same reasoning as zchunk2 of wl_fused2.hip): minimise rounds of 512 workgroups × (planes per chunk + warm-up)
+  const int warm = (H == 3 ? 5 : 3) + 3;
+  long best = -1; int best_zc = np;
+  for (int chunks = 1; chunks <= np; chunks++) {
+    const int zc = (np + chunks - 1) / chunks;
+    if (zc < (zmin_env ? zmin_env : 4)) break;
+    const int nch = (np + zc - 1) / zc;
+    const long W = (long)nt * nch;
+    long cost = ((W + 511) / 512) * (zc + warm);
+    if (W < 512) cost = (long)((zc + warm) * 1.25);
+    if (best < 0 || cost < best) { best = cost; best_zc = zc; }
+  }
+  return best_zc;
 }
 // GaussSeidelRB!(it=4,ω): emid and rout are scratch arrays of the level (ghosts zero); on return eps holds the final ϵ,
 // rout the new residual (caller swaps r<->rout) and x is updated in place.
