@@ -619,3 +619,22 @@ def test_periodic_3d_steps_match_oracle(w, oracle, perdir):
         assert sg.pois_n[-2:] == so.pois_n[-2:]
         assert np.abs(sg.field("u") - so.u).max() < 3e-5, step
         assert np.abs(sg.field("p") - so.p).max() < 3e-4, step
+
+
+def test_body_mask_fast_path_is_bit_identical(w):
+    """BDIM!'s u pass skips μ₁, V and the f neighbours in workgroups where μ₁ ≡ 0 and V ≡ 0 (mask refreshed by measure!/update!):
+    same bits as the general expression, also after the body moved (re-measure) and with the convective exit."""
+    N, R = 64, 8.0
+    res = {}
+    for fm in (1, 0):
+        sim = w.FusedSimulation((N, N, N), (1, 0, 0), 2 * R, U=1, nu=2 * R / 250, has_body=True, exitBC=True)
+        sim.set_option("farmask", fm)
+        sim.measure_sphere_((N / 4, N / 2 - 1, N / 2 - 1), R, 1.0)
+        for _ in range(2):
+            sim.mom_step_()
+        sim.measure_sphere_((N / 4 + 3.5, N / 2 + 2, N / 2 - 1), R, 1.0)      # the mask follows the body
+        for _ in range(2):
+            sim.mom_step_()
+        res[fm] = (sim.field("u"), sim.field("p"), sim.pois_n)
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

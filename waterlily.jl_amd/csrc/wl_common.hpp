@@ -210,7 +210,9 @@ void jacobi_march_enable(int on);
 bool conv_march_ok(const GridX& g);
 int conv_march(float* r, const float* u, const GridX& g, float nu, unsigned per, int scheme, int kfirst, int klast, const void* bdim_args, hipStream_t s);
 int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, hipStream_t s);
-int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s);
+int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s, const unsigned char* far = nullptr);
+size_t body_mask_bytes(const GridX& g);
+int body_mask(unsigned char* far, const float* V, const float* mu1, const GridX& g, hipStream_t s);
 int scale_u(float* u, const GridX& g, float sc, hipStream_t s);
 int div(float* z, const float* u, const GridX& g, hipStream_t s);
 int div_scale(float* z, float* x, const float* u, const GridX& g, float dt, hipStream_t s);   // z=div(u); x*=dt  (fused, src/Flow.jl:225)

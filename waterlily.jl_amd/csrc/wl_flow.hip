@@ -154,14 +154,39 @@ __global__ void k_bdim_f(GridX g, float* __restrict__ f, const float* __restrict
   }
 }
 // pass B: u[I,i] = (u*pre + (μddn(I,μ₁,f) + V + μ₀ f)) * post   on the interior
+// far[b] = 1: every cell of workgroup b has μ₁ ≡ 0 and V ≡ 0 (far from the body) — computed once per measure!/update!.  Those
+// workgroups skip the 48 B/cell of μ₁ and V and the six neighbour values of f; the expression degenerates to the same bits
+// ((±0)/2 + (+0)) + μ₀·f = μ₀·f.
+template <int D>
+__global__ void k_body_mask(GridX g, const float* __restrict__ V, const float* __restrict__ mu1, unsigned char* __restrict__ far) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  int bad = 0;
+  if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
+    const long o = m + (long)(g.k0 + pz) * g.sz;
+    for (int a = 0; a < D; a++) { if (V[(long)a * g.cs + o] != 0.f) bad = 1; for (int b = 0; b < D; b++) if (mu1[(long)(a + b * D) * g.cs + o] != 0.f) bad = 1; }
+  }
+  bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) far[blockIdx.x] = bad ? 0 : 1;
+}
 template <int D>
 __global__ void k_bdim_u(GridX g, float* __restrict__ u, const float* __restrict__ f, const float* __restrict__ V, const float* __restrict__ mu0, const float* __restrict__ mu1,
-                         float pre, float post, int scale_after) {
+                         float pre, float post, int scale_after, const unsigned char* __restrict__ far) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
   const long o = m + (long)(g.k0 + pz) * g.sz;
   const long st[3] = {1, g.sy, g.sz};
+  if (far && far[blockIdx.x]) {
+    for (int a = 0; a < D; a++) {
+      const long oa = (long)a * g.cs + o;
+      const float x = (0.f / 2 + 0.f) + mu0[oa] * f[oa];
+      float un = (pre == 0.f) ? x : (u[oa] * pre + x);
+      if (scale_after) un = un * post;
+      u[oa] = un;
+    }
+    return;
+  }
   for (int a = 0; a < D; a++) {
     const long oa = (long)a * g.cs + o;
     float s = 0.f;
@@ -589,8 +614,13 @@ int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, 
   } else {
     const long n = g.cs * g.D;
     hipLaunchKernelGGL(k_bdim_f, dim3(grid1d((size_t)n)), dim3(WL_BLOCK), 0, s, g, f, u0, V, dt, n);
-    DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, scale_after);
+    DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, scale_after, (const unsigned char*)nullptr);
   }
+  WL_LAUNCH_CHECK(); return 0;
+}
+size_t body_mask_bytes(const GridX& g) { return (size_t)wl_plane_grid(g, g.k1 - g.k0).x; }
+int body_mask(unsigned char* far, const float* V, const float* mu1, const GridX& g, hipStream_t s) {
+  DSEL(g.D, k_body_mask, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, V, mu1, far);
   WL_LAUNCH_CHECK(); return 0;
 }
 int accelerate(float* r, const GridX& g, const float* a, hipStream_t s) {
@@ -603,8 +633,8 @@ int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, 
   hipLaunchKernelGGL(k_bdim_f, dim3(grid1d((size_t)n)), dim3(WL_BLOCK), 0, s, g, f, u0, V, dt, n);
   WL_LAUNCH_CHECK(); return 0;
 }
-int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s) {
-  DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, (post != 1.f) ? 1 : 0);
+int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s, const unsigned char* far) {
+  DSEL(g.D, k_bdim_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, f, V, mu0, mu1, pre, post, (post != 1.f) ? 1 : 0, far);
   WL_LAUNCH_CHECK(); return 0;
 }
 int scale_u(float* u, const GridX& g, float sc, hipStream_t s) { DSEL(g.D, k_scale_u, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, u, sc); WL_LAUNCH_CHECK(); return 0; }

@@ -258,7 +258,7 @@ struct wl_sim {
   float acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};   // at t₀ (predictor) and t₁ (corrector)
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
-  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); }
+  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); if (farmask) (void)hipFree(farmask); }
 
   // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
   // On slabs the exchange runs on the communicator's own stream; the compute stream waits for it (sync_u) only where the halo
@@ -295,14 +295,22 @@ struct wl_sim {
     }
     return wl::conv_diff(f, uadv, sigma, G, d.nu, d.perdir_mask, d.scheme, s);
   }
+  unsigned char* farmask = nullptr;   // per workgroup of BDIM's u pass: 1 = μ₁ ≡ 0 and V ≡ 0 there (refreshed by measure!/update!)
+  bool use_farmask = true, mask_valid = false;   // handing out V or μ₁ (wl_sim_field) invalidates the mask until the next update!
+  int refresh_body_mask(hipStream_t s) {
+    if (!d.has_body || !mu1 || !V) return 0;
+    if (!farmask) WL_HIP(hipMalloc((void**)&farmask, wl::body_mask_bytes(G)));
+    mask_valid = true;
+    return wl::body_mask(farmask, V, mu1, G, s);
+  }
   int bdim_step(float pre, float post, hipStream_t s) {
     ProfScope pb(WL_PROF_BDIM, s);
-    if (d.has_body && comm) {   // μddn reads f[I±δz] across the slab face: exchange f between the two passes
+    if (d.has_body) {
       WL_TRY(wl::bdim_f(f, u0, V, G, dt.back(), s));
-      WL_TRY(wl::halo(comm, f, G, d.D, 1, s));
-      return wl::bdim_u(u, f, V, mu0, mu1, G, pre, post, s);
+      if (comm) WL_TRY(wl::halo(comm, f, G, d.D, 1, s));   // μddn reads f[I±δz] across the slab face: exchange f between the two passes
+      return wl::bdim_u(u, f, V, mu0, mu1, G, pre, post, s, (use_farmask && mask_valid) ? farmask : nullptr);
     }
-    return wl::bdim(u, u0, f, d.has_body ? V : nullptr, mu0, d.has_body ? mu1 : nullptr, G, dt.back(), pre, post, s);
+    return wl::bdim(u, u0, f, nullptr, mu0, nullptr, G, dt.back(), pre, post, s);
   }
   int exit_bc(hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
@@ -488,6 +496,7 @@ int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
 float* wl_sim_field(wl_sim* s, const char* name) {
   const std::string n(name);
   (void)s->sync_u(0);        // the caller is about to read or write the arrays: finish an exchange that is still in flight
+  if (n == "V" || n == "mu1") s->mask_valid = false;
   if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") return s->p;
   if (n == "sigma") return s->sigma; if (n == "V") return s->V; if (n == "mu0") return s->mu0; if (n == "mu1") return s->mu1;
   return nullptr;
@@ -514,6 +523,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
+  if (n == "farmask") { s->use_farmask = value != 0; return 0; }
   if (n == "store_f") { s->store_f = value != 0; return 0; }
   if (n == "overlap") { WL_TRY(s->sync_u(0)); s->use_overlap = value != 0; return 0; }
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
@@ -523,7 +533,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
-int wl_sim_update(wl_sim* s, void* st) { return s->mg->update(wl_stream(st)); }
+int wl_sim_update(wl_sim* s, void* st) { WL_TRY(s->refresh_body_mask(wl_stream(st))); return s->mg->update(wl_stream(st)); }
 int wl_sim_set_forcing(wl_sim* s, const float* U1, const float* a0, const float* a1) {
   const int D = s->d.D;
   if (U1) for (int c = 0; c < D; c++) s->d.uBC[c] = U1[c];
@@ -572,6 +582,7 @@ int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* s
   WL_TRY(wl::bc_vec(s->mu0, G, zero, 0, s->d.perdir_mask, q));                                                                     // Body.jl:49
   WL_TRY(wl::bc_vec(s->V, G, zero, s->d.exitBC, s->d.perdir_mask, q));                                                              // Body.jl:50
   WL_TRY(wl::halo(s->comm, s->mu0, G, D, 2, q)); WL_TRY(wl::halo(s->comm, s->V, G, D, 2, q));
+  WL_TRY(s->refresh_body_mask(q));
   return s->mg->update(q);                                                                                                          // WaterLily.jl:148
 }
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {
