@@ -59,6 +59,20 @@ def w():
     return w
 
 
+def test_julia_binding_calls_only_declared_symbols():
+    """every ccall target of waterlily.jl_amd/julia/WaterLilyHIPExt.jl (the reference-side binding of INTEGRATION.md) is declared in
+    include/wlhip.h and bound by the ctypes table — the binding cannot be executed here (no Julia), its symbol list can be checked"""
+    import re
+    from waterlily_jl_amd._lib import SIGNATURES
+    src = open(os.path.join(ROOT, "waterlily.jl_amd", "julia", "WaterLilyHIPExt.jl")).read()
+    header = open(os.path.join(ROOT, "include", "wlhip.h")).read()
+    syms = sorted(set(re.findall(r"\(:(wl_[A-Za-z0-9_]+)", src)))
+    assert len(syms) > 30
+    for sname in syms:
+        assert re.search(r"\b" + sname + r"\s*\(", header), sname
+        assert sname in SIGNATURES, sname
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tag", ["k2", "k3"])
 def test_hip_kernels_reproduce_golden(w, tag):
