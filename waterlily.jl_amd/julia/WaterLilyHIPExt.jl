@@ -80,6 +80,25 @@ const HML = MultiLevelPoisson{Float32,<:HA}
 BC!(a::HA, U::Union{Tuple,AbstractVector}, saveexit=false, perdir=(), t=0) =
     chk(ccall((:wl_bc_vec, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{NTuple{3,Cfloat}}, Cint, Cuint, Ptr{Cvoid}),
               a.ptr, vgrid(a), ntuple(i -> i <= length(U) ? Cfloat(U[i]) : 0f0, 3), saveexit, pmask(perdir), C_NULL))
+# BC!(a,uBC::Function,…) src/core.jl:201-219: the closure is evaluated on the host over the boundary shell (two layers per side, all
+# the kernel reads) and handed over as a table; the device applies the reference's sequential edge/corner semantics.
+function BC!(a::HA, uBC::Function, saveexit=false, perdir=(), t=0)
+    N, n = WaterLily.size_u(a); T = eltype(a)
+    tab = zeros(T, size(a))
+    for j in 1:n, s in (1, 2, N[j]-1, N[j]), i in 1:n
+        j in perdir && continue
+        for I in WaterLily.slice(N, s, j); tab[I, i] = uBC(i, loc(i, I, T), t); end
+    end
+    Ub = HipArray(tab)
+    chk(ccall((:wl_bc_vec_fn, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cuint, Ptr{Cvoid}), a.ptr, Ub.ptr, vgrid(a), saveexit, pmask(perdir), C_NULL))
+end
+# accelerate!(r,t,g,U) src/Flow.jl:69-73 for closures: tabulate g(i,x,t)+∂ₜU(i,x,t) on the host, add on the device
+function WaterLily.accelerate!(r::HA, t, f::Function)
+    T = eltype(r); tab = zeros(T, size(r))
+    for Ii in CartesianIndices(tab); tab[Ii] = f(last(Ii), loc(Ii, T), t); end
+    G = HipArray(tab)
+    chk(ccall((:wl_accelerate_field, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), r.ptr, G.ptr, vgrid(r), C_NULL))
+end
 perBC!(a::HA, perdir::Tuple) = isempty(perdir) ? nothing :
     chk(ccall((:wl_bc_per_scalar, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cuint, Ptr{Cvoid}), a.ptr, sgrid(a), pmask(perdir), C_NULL))
 exitBC!(u::HA, u⁰::HA, Δt) = chk(ccall((:wl_exit_bc, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}), u.ptr, u⁰.ptr, vgrid(u), Δt, C_NULL))
@@ -152,6 +171,15 @@ function solver!(m::HipMultiLevel; tol=2e-3, itmx=32)
     n = Ref{Cint}(); r1 = Ref{Cdouble}(); ri = Ref{Cfloat}()
     chk(ccall((:wl_mg_solve, libwlhip), Cint, (Ptr{Cvoid}, Cdouble, Cint, Ref{Cint}, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}), m.handle, tol, itmx, n, r1, ri, C_NULL))
     push!(m.n, n[])
+end
+
+# temporal averages (src/Metrics.jl:236-252) on device arrays
+function WaterLily.update!(m::WaterLily.MeanFlow{Float32,<:HA}, flow::WaterLily.AbstractFlow)
+    dt = WaterLily.time(flow) - m.t[end]
+    ε = length(m.t) == 1 ? 1f0 : dt / (dt + WaterLily.time(m) + eps(Float32))
+    chk(ccall((:wl_meanflow_update, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}),
+              m.P.ptr, m.U.ptr, m.uu_stats ? m.UU.ptr : C_NULL, flow.p.ptr, flow.u.ptr, sgrid(flow.p), ε, C_NULL))
+    push!(m.t, m.t[end] + dt)
 end
 
 export HipArray, HipMultiLevel
