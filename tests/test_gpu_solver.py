@@ -621,14 +621,16 @@ def test_periodic_3d_steps_match_oracle(w, oracle, perdir):
         assert np.abs(sg.field("p") - so.p).max() < 3e-4, step
 
 
-def test_body_mask_fast_path_is_bit_identical(w):
-    """BDIM!'s u pass skips μ₁, V and the f neighbours in workgroups where μ₁ ≡ 0 and V ≡ 0 (mask refreshed by measure!/update!):
-    same bits as the general expression, also after the body moved (re-measure) and with the convective exit."""
+@pytest.mark.parametrize("exitBC", [True, False])
+def test_body_mask_fast_path_is_bit_identical(w, exitBC):
+    """Far from the body BDIM! degenerates to the NoBody form: (i) its u pass skips μ₁, V and the f neighbours in workgroups where
+    μ₁ ≡ 0 and V ≡ 0; (ii) without the convective exit conv_diff! applies it directly (k_conv_diff<…,FUSE=2>) and the two-pass kernels
+    run on the near workgroups only.  Masks are refreshed by measure!/update!: same bits as the general path, also after the body moved."""
     N, R = 64, 8.0
     res = {}
     for fm in (1, 0):
-        sim = w.FusedSimulation((N, N, N), (1, 0, 0), 2 * R, U=1, nu=2 * R / 250, has_body=True, exitBC=True)
-        sim.set_option("farmask", fm)
+        sim = w.FusedSimulation((N, N, N), (1, 0, 0), 2 * R, U=1, nu=2 * R / 250, has_body=True, exitBC=exitBC)
+        sim.set_option("farmask", fm); sim.set_option("hybrid", fm)
         sim.measure_sphere_((N / 4, N / 2 - 1, N / 2 - 1), R, 1.0)
         for _ in range(2):
             sim.mom_step_()

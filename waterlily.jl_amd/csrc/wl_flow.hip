@@ -2,6 +2,7 @@
 // generic array ops.  Reference semantics: /root/reference/src/Flow.jl, src/core.jl (file:line per kernel).
 // Arithmetic order follows the reference statement by statement (-ffp-contract=off).
 #include <cstdlib>
+#include <vector>
 
 #include "wl_common.hpp"
 #include "wl_conv_cell.hpp"
@@ -81,6 +82,35 @@ __global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, fl
   const IDX st[3] = {1, (IDX)g.sy, (IDX)g.sz};
   float out[3];
   cd_cell<D, SCH, PER, IDX, 0, 0>(g, u, o, I, N, st, nu, per, nullptr, out);
+  if (FUSE == 2) {
+    // Flow with a body.  Far from it (μ₁ ≡ 0, V ≡ 0 in this workgroup's cells of this plane) BDIM! degenerates to the NoBody form and is
+    // applied here; near it the raw r goes to f for the two-pass BDIM! kernels, which run on the near workgroups only.  Far
+    // workgroups keep f = u⁰+Δt·r only where a near cell's μddn reads it (needf).
+    bool in = interior_ij(g, i, j);
+    if (D == 3) in = in && k >= g.k0 && k < g.k1;
+    const long mi = (long)k * bd.nbm + (m / WL_BLOCK);
+    if (bd.near[mi]) {
+#pragma unroll
+      for (int a = 0; a < D; a++) r[(long)a * g.cs + o] = out[a];
+      return;
+    }
+    const bool keepf = bd.store_all || bd.needf[mi];
+    const bool m0load = bd.m0var[mi] != 0;
+#pragma unroll
+    for (int a = 0; a < D; a++) {
+      const long oa = (long)a * g.cs + o;
+      const float fn = bd.u0[oa] + bd.dt * out[a] - 0.f;
+      if (keepf) r[oa] = fn;
+      if (in) {
+        const float m0 = m0load ? bd.mu0[oa] : wl::wl_cl_coef(I[a], N[a], 1.f);       // verified per workgroup by k_body_mask2
+        const float xx = (0.f / 2 + 0.f) + m0 * fn;
+        float un = (bd.pre == 0.f) ? xx : (u[oa] * bd.pre + xx);
+        if (bd.scale_after) un = un * bd.post;
+        bd.uout[oa] = un;
+      }
+    }
+    return;
+  }
   if (FUSE) {
     bool in = interior_ij(g, i, j);
     if (D == 3) in = in && k >= g.k0 && k < g.k1;
@@ -197,6 +227,69 @@ __global__ void k_bdim_u(GridX g, float* __restrict__ u, const float* __restrict
     float un = (pre == 0.f) ? x : (u[oa] * pre + x);
     if (scale_after) un = un * post;
     u[oa] = un;
+  }
+}
+// ---- body-aware split of conv_diff!+BDIM! (k_conv_diff<…,FUSE=2>): masks indexed by (plane k, in-plane workgroup m/256) -------------
+template <int D>
+__global__ void k_body_mask2(GridX g, const float* __restrict__ V, const float* __restrict__ mu1, const float* __restrict__ mu0, unsigned char* __restrict__ near,
+                             unsigned char* __restrict__ needf, unsigned char* __restrict__ m0var, int nbm) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = pz;
+  const long o = m + (long)k * g.sz;
+  {
+    const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2}, N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
+    bool var = false;
+    for (int a = 0; a < D; a++) if (mu0[(long)a * g.cs + o] != wl::wl_cl_coef(I[a], N[a], 1.f)) var = true;
+    if (var) m0var[(long)k * nbm + m / WL_BLOCK] = 1;
+  }
+  bool nz1 = false, nzv = false;
+  for (int a = 0; a < D; a++) { if (V[(long)a * g.cs + o] != 0.f) nzv = true; for (int b = 0; b < D; b++) if (mu1[(long)(a + b * D) * g.cs + o] != 0.f) nz1 = true; }
+  if (nz1 || nzv) near[(long)k * nbm + m / WL_BLOCK] = 1;
+  if (nz1) {   // μddn of this cell reads f at its six neighbours
+    const long st[3] = {1, g.sy, g.sz};
+    for (int b = 0; b < D; b++) for (int sg = -1; sg <= 1; sg += 2) {
+      long mm = m; int kk = k;
+      if (b == 2) kk += sg; else mm += sg * st[b];
+      if (kk < 0 || kk >= g.nz || mm < 0 || mm >= g.sz) continue;
+      needf[(long)kk * nbm + mm / WL_BLOCK] = 1;
+    }
+  }
+}
+// pass A on the near workgroups: f = u⁰ + Δt·f − V (every cell of the workgroup)
+// (both near-workgroup kernels are launched over the bounding box of the near workgroups only: blockIdx.x ↔ in-plane workgroup b0+x,
+//  blockIdx.y ↔ plane kb+y — dispatching the whole grid for a body that fills 2 % of it would cost more than the work)
+template <int D>
+__global__ void k_bdim_f_m(GridX g, float* __restrict__ f, const float* __restrict__ u0, const float* __restrict__ V, float dt, const unsigned char* __restrict__ near, int nbm, int b0, int kb) {
+  int i, j;
+  const long m = (long)(b0 + (int)blockIdx.x) * WL_BLOCK + threadIdx.x;
+  const int pz = kb + (int)blockIdx.y;
+  if (!cell_ij(g, m, i, j)) return;
+  if (!near[(long)pz * nbm + m / WL_BLOCK]) return;
+  const long o = m + (long)pz * g.sz;
+  for (int a = 0; a < D; a++) { const long oa = (long)a * g.cs + o; f[oa] = u0[oa] + dt * f[oa] - V[oa]; }
+}
+// pass B on the near workgroups: u_out[I,i] = (u_in·pre + (μddn(I,μ₁,f) + V + μ₀ f))·post   on the interior
+template <int D>
+__global__ void k_bdim_u_m(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ f, const float* __restrict__ V, const float* __restrict__ mu0,
+                           const float* __restrict__ mu1, float pre, float post, int scale_after, const unsigned char* __restrict__ near, int nbm, int b0, int kb) {
+  int i, j;
+  const long m = (long)(b0 + (int)blockIdx.x) * WL_BLOCK + threadIdx.x;
+  const int k = kb + (int)blockIdx.y;
+  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  if (k < g.k0 || k >= g.k1) return;
+  if (!near[(long)k * nbm + m / WL_BLOCK]) return;
+  const long o = m + (long)k * g.sz;
+  const long st[3] = {1, g.sy, g.sz};
+  for (int a = 0; a < D; a++) {
+    const long oa = (long)a * g.cs + o;
+    float s = 0.f;
+    for (int b = 0; b < D; b++) s += mu1[(long)(a + b * D) * g.cs + o] * (f[oa + st[b]] - f[oa - st[b]]);     // μddn :20-26
+    const float x = (s / 2 + V[oa]) + mu0[oa] * f[oa];
+    float un = (pre == 0.f) ? x : (uin[oa] * pre + x);
+    if (scale_after) un = un * post;
+    uout[oa] = un;
   }
 }
 // NoBody fast path (μ₁≡0, V≡0): both passes in one kernel over all cells
@@ -559,10 +652,11 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0, 0, {0.f, 0.f, 0.f}};
   const BdimArgs ba = bd ? *bd : b0;
   const bool march = D == 3 && wl::conv_march_ok(g);   // z-marching variant (wl_convm.hip): same arithmetic, the z-star in registers
-  if (march) WL_TRY(wl::conv_march(r, u, g, nu, per, SCH, kfirst, klast, bd, s));
+  if (march && !(bd && bd->near)) WL_TRY(wl::conv_march(r, u, g, nu, per, SCH, kfirst, klast, bd, s));
 #define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \
   hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba)
-  if (march) {}
+  if (march && !(bd && bd->near)) {}
+  else if (bd && bd->near) { if (per) { if (small) WL_CD(1, int, 2); else WL_CD(1, long, 2); } else { if (small) WL_CD(0, int, 2); else WL_CD(0, long, 2); } }
   else if (bd) { if (per) { if (small) WL_CD(1, int, 1); else WL_CD(1, long, 1); } else { if (small) WL_CD(0, int, 1); else WL_CD(0, long, 1); } }
   else    { if (per) { if (small) WL_CD(1, int, 0); else WL_CD(1, long, 0); } else { if (small) WL_CD(0, int, 0); else WL_CD(0, long, 0); } }
 #undef WL_CD
@@ -606,6 +700,40 @@ int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, co
   if (u_out == u_adv) { wl_set_error("conv_diff_bdim: output aliases the advecting field"); return WL_EINVAL; }
   BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, cl.on, {cl.c[0], cl.c[1], cl.c[2]}};
   return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd, ka, kb, q1) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
+}
+// conv_diff!+BDIM! for a flow with a body (see k_conv_diff<…,FUSE=2>): u_out ≠ u_adv; f is an output array (raw r near the body)
+int conv_diff_bdim_body(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
+                        float dt, float pre, float post, const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, int nbm, int store_all, hipStream_t s) {
+  if (u_out == u_adv || !near || !needf || !m0var || !f) { wl_set_error("conv_diff_bdim_body: bad arguments"); return WL_EINVAL; }
+  BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, 0, {0.f, 0.f, 0.f}, near, needf, nbm, store_all, m0var};
+  return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
+}
+int body_masks_nbm(const GridX& g) { return 8 * wl_strip_blocks(g); }
+int body_masks(unsigned char* near, unsigned char* needf, unsigned char* m0var, const float* V, const float* mu1, const float* mu0, const GridX& g, hipStream_t s) {
+  const int nbm = body_masks_nbm(g);
+  WL_HIP(hipMemsetAsync(near, 0, (size_t)nbm * g.nz, s)); WL_HIP(hipMemsetAsync(needf, 0, (size_t)nbm * g.nz, s)); WL_HIP(hipMemsetAsync(m0var, 0, (size_t)nbm * g.nz, s));
+  DSEL(g.D, k_body_mask2, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, V, mu1, mu0, near, needf, m0var, nbm);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int bdim_near(float* uout, const float* uin, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post,
+              const unsigned char* near, int nbm, const int* box, hipStream_t s) {
+  if (box[1] < box[0] || box[3] < box[2]) return 0;            // no near workgroup at all
+  const dim3 grid((unsigned)(box[1] - box[0] + 1), (unsigned)(box[3] - box[2] + 1), 1);
+  DSEL(g.D, k_bdim_f_m, grid, dim3(WL_BLOCK), 0, s, g, f, u0, V, dt, near, nbm, box[0], box[2]);
+  DSEL(g.D, k_bdim_u_m, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, (const float*)f, V, mu0, mu1, pre, post, (post != 1.f) ? 1 : 0, near, nbm, box[0], box[2]);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// bounding box {b0,b1,k0,k1} (inclusive) of the near workgroups; host-synchronising (measure!/update! time only)
+int body_masks_box(const unsigned char* near, const GridX& g, int* box, hipStream_t s) {
+  const int nbm = body_masks_nbm(g);
+  std::vector<unsigned char> h((size_t)nbm * g.nz);
+  WL_HIP(hipMemcpyAsync(h.data(), near, h.size(), hipMemcpyDeviceToHost, s));
+  WL_HIP(hipStreamSynchronize(s));
+  box[0] = nbm; box[1] = -1; box[2] = g.nz; box[3] = -1;
+  for (int k = 0; k < g.nz; k++) for (int b = 0; b < nbm; b++) if (h[(size_t)k * nbm + b]) {
+    if (b < box[0]) box[0] = b; if (b > box[1]) box[1] = b; if (k < box[2]) box[2] = k; if (k > box[3]) box[3] = k;
+  }
+  return 0;
 }
 int bdim(float* u, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post, hipStream_t s) {
   const int scale_after = (post != 1.f) ? 1 : 0;

@@ -258,7 +258,7 @@ struct wl_sim {
   float acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};   // at t₀ (predictor) and t₁ (corrector)
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
-  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); if (farmask) (void)hipFree(farmask); }
+  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); if (farmask) (void)hipFree(farmask); if (mnear) (void)hipFree(mnear); if (mneedf) (void)hipFree(mneedf); if (mm0var) (void)hipFree(mm0var); }
 
   // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
   // On slabs the exchange runs on the communicator's own stream; the compute stream waits for it (sync_u) only where the halo
@@ -297,11 +297,27 @@ struct wl_sim {
   }
   unsigned char* farmask = nullptr;   // per workgroup of BDIM's u pass: 1 = μ₁ ≡ 0 and V ≡ 0 there (refreshed by measure!/update!)
   bool use_farmask = true, mask_valid = false;   // handing out V or μ₁ (wl_sim_field) invalidates the mask until the next update!
+  // body-aware conv_diff!+BDIM! (k_conv_diff<…,FUSE=2>): near / needf masks per (plane, in-plane workgroup)
+  unsigned char *mnear = nullptr, *mneedf = nullptr, *mm0var = nullptr;
+  int near_box[4] = {0, -1, 0, -1};   // {b0,b1,k0,k1}: bounding box of the near workgroups
+  bool use_hybrid = true;
+  bool hybrid_ok() const { return d.has_body && use_hybrid && mask_valid && mnear && us && !comm && !forcing && !d.exitBC; }
   int refresh_body_mask(hipStream_t s) {
     if (!d.has_body || !mu1 || !V) return 0;
     if (!farmask) WL_HIP(hipMalloc((void**)&farmask, wl::body_mask_bytes(G)));
+    if (!mnear) { const size_t nb = (size_t)wl::body_masks_nbm(G) * (size_t)G.nz; WL_HIP(hipMalloc((void**)&mnear, nb)); WL_HIP(hipMalloc((void**)&mneedf, nb)); WL_HIP(hipMalloc((void**)&mm0var, nb)); }
     mask_valid = true;
+    WL_TRY(wl::body_masks(mnear, mneedf, mm0var, V, mu1, mu0, G, s));
+    WL_TRY(wl::body_masks_box(mnear, G, near_box, s));
     return wl::body_mask(farmask, V, mu1, G, s);
+  }
+  // conv_diff!(f,uadv) + BDIM! with a body: fused NoBody form far from the body, two-pass BDIM! on the near workgroups only
+  int conv_bdim_body(const float* uadv, float* uout, float pre, float post, hipStream_t s) {
+    WL_TRY(sync_u(s));
+    { ProfScope pc(WL_PROF_CONVDIFF, s);
+      WL_TRY(wl::conv_diff_bdim_body(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, mnear, mneedf, mm0var, wl::body_masks_nbm(G), store_f ? 1 : 0, s)); }
+    ProfScope pb(WL_PROF_BDIM, s);
+    return wl::bdim_near(uout, u, u0, f, V, mu0, mu1, G, dt.back(), pre, post, mnear, wl::body_masks_nbm(G), near_box, s);
   }
   int bdim_step(float pre, float post, hipStream_t s) {
     ProfScope pb(WL_PROF_BDIM, s);
@@ -314,6 +330,10 @@ struct wl_sim {
   }
   int exit_bc(hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
+    if (hybrid_ok()) {
+      WL_TRY(conv_bdim_body(u0, u, 0.f, 1.f, s));
+      return bc_u(s);
+    }
     if (us && !d.has_body && !forcing) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
       ProfScope pc(WL_PROF_CONVDIFF, s);
       if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
@@ -331,6 +351,11 @@ struct wl_sim {
     return 0;
   }
   int correct(hipStream_t s) {                                                           // mom_correct! :205-210
+    if (hybrid_ok()) {
+      WL_TRY(conv_bdim_body(u, us, 1.f, 0.5f, s));
+      std::swap(u, us);
+      return bc_u(s);
+    }
     if (us && !d.has_body && !forcing) {   // the advecting field is u itself: write the new u to the spare array and swap
       { ProfScope pc(WL_PROF_CONVDIFF, s);
         if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
@@ -462,7 +487,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   float* given[8] = {desc->u, desc->u0, desc->f, desc->p, desc->sigma, desc->V, desc->mu0, desc->mu1};
   const size_t sz[8] = {nc * D, nc * D, nc * D, nc, nc, nc * D, nc * D, nc * D * D};
   size_t total = 0;
-  const bool want_us = !desc->u && !desc->u0 && !desc->exitBC && !desc->has_body;
+  const bool want_us = !desc->u && !desc->u0 && !desc->exitBC;   // spare velocity array of the out-of-place fused kernels
   if (want_us) total += nc * D;
   total += nc;   // ps
   for (int q = 0; q < 8; q++) if (!given[q] && !(q == 7 && !desc->has_body) && !(q == 5 && !desc->has_body)) total += sz[q];
@@ -496,7 +521,7 @@ int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
 float* wl_sim_field(wl_sim* s, const char* name) {
   const std::string n(name);
   (void)s->sync_u(0);        // the caller is about to read or write the arrays: finish an exchange that is still in flight
-  if (n == "V" || n == "mu1") s->mask_valid = false;
+  if (n == "V" || n == "mu1" || n == "mu0") s->mask_valid = false;
   if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") return s->p;
   if (n == "sigma") return s->sigma; if (n == "V") return s->V; if (n == "mu0") return s->mu0; if (n == "mu1") return s->mu1;
   return nullptr;
@@ -523,6 +548,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
+  if (n == "hybrid") { s->use_hybrid = value != 0; return 0; }
   if (n == "farmask") { s->use_farmask = value != 0; return 0; }
   if (n == "store_f") { s->store_f = value != 0; return 0; }
   if (n == "overlap") { WL_TRY(s->sync_u(0)); s->use_overlap = value != 0; return 0; }
