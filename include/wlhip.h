@@ -137,10 +137,11 @@ float* wl_mg_level_field(const wl_mg* mg, int level, const char* name);
 int wl_mg_vcycle(wl_mg* mg, int level, float omega, void* stream);
 int wl_mg_smooth(wl_mg* mg, int level, int it, float omega, void* stream);      /* smooth! = GaussSeidelRB! on one level (:106) */
 int wl_mg_level_is_const(const wl_mg* mg, int level);   /* 1 if the level's L was verified to be 'constant inside, 0 on wall faces' */
-int wl_mg_smoother_kind(const wl_mg* mg, int level);   /* how smooth! runs on the level: 0 one kernel per pass, 1 temporally blocked, 2 blocked pair kernels */
+int wl_mg_smoother_kind(const wl_mg* mg, int level);   /* how smooth! runs on the level: 0 one kernel per pass, 1 temporally blocked, 2 blocked pair kernels,
+                                                          3 z-split (pair kernels away from the body, general blocked kernels near it) */
 int wl_mg_set_fused(wl_mg* mg, int on);   /* bit0 (default 1): temporally blocked smoother on eligible levels, 0: one kernel per pass;
                                              bit1: do not store the final ϵ (scratch of the reference that nothing reads again);
-                                             bit2: no pair kernels; bit3: no single-launch coarse tail */
+                                             bit2: no pair kernels; bit3: no single-launch coarse tail; bit4: no z-split on body levels */
 /* solver!(ml;tol,itmx): returns iterations in *host_n and the last L₁/L∞; appends to the n history. */
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, void* stream);
 int wl_mg_history(const wl_mg* mg, int16_t* host_out, int cap);                        /* pois.n :66 */

@@ -640,3 +640,27 @@ def test_body_mask_fast_path_is_bit_identical(w, exitBC):
         res[fm] = (sim.field("u"), sim.field("p"), sim.pois_n)
     assert res[0][2] == res[1][2]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+@pytest.mark.parametrize("exitBC", [True, False])
+def test_zsplit_smoother_on_body_levels_is_bit_identical(w, exitBC):
+    """smooth! on a level with a body: the planes at least four away from every cell whose coefficients leave the NoBody pattern
+    run the constant-coefficient pair kernels, the planes around the body the general blocked kernels (plane sub-ranges of the same
+    launchers).  Same bits as the general kernels over the whole level, also after the body moved along z."""
+    n = (128, 64, 96)
+    R = 8.0
+    res = {}
+    for zs in (1, 0):
+        sim = w.FusedSimulation(n, (1, 0, 0), 2 * R, U=1, nu=2 * R / 250, has_body=True, exitBC=exitBC)
+        sim.set_option("zsplit", 2 if zs else 0)         # 2: also on levels below the size where the split pays (set before measure!)
+        sim.measure_sphere_((n[0] / 4, n[1] / 2 - 1, n[2] / 2 - 1), R, 1.0)
+        assert sim.smoother_kinds()[0] == (3 if zs else 1)
+        for _ in range(2):
+            sim.mom_step_()
+        sim.measure_sphere_((n[0] / 4 + 1.5, n[1] / 2, n[2] / 2 + 20.5), R, 1.0)
+        assert sim.smoother_kinds()[0] == (3 if zs else 1)
+        for _ in range(2):
+            sim.mom_step_()
+        res[zs] = (sim.field("u"), sim.field("p"), sim.pois_n)
+    assert res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])

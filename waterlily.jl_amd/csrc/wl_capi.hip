@@ -5,6 +5,8 @@
 #include <vector>
 
 #include "wl_common.hpp"
+#include <algorithm>
+
 #include "wl_mg.hpp"
 
 static thread_local std::string g_err;
@@ -122,7 +124,7 @@ int wl_mg::update(hipStream_t s) {                                              
   }
   // constant-coefficient detection (exact, on device): only the levels that run the specialised kernels are checked
   for (size_t l = 0; l < lv.size(); l++) {
-    lv[l].cl.on = 0;
+    lv[l].cl.on = 0; lv[l].part = false;
     if (use_constl && !perdir && (l == 0 || wl::gsrb_fused_ok(lv[l].x_, perdir, lv[l].dist) || (lv[l].dist && wl::gsrb_pair_geom_ok(lv[l].x_)))) {
       WL_TRY(wl::check_const_L(lv[l].L, lv[l].x_, &lv[l].cl, (int*)(ws.res_f + 7), s));
       if (lv[l].dist && comm && comm->size > 1) {   // every rank must take the same path (the slab kernels differ in their halo exchanges)
@@ -132,6 +134,15 @@ int wl_mg::update(hipStream_t s) {                                              
         WL_HIP(hipMemcpyAsync(&any, ws.res_f + 7, sizeof(float), hipMemcpyDeviceToHost, s));
         WL_HIP(hipStreamSynchronize(s));
         if (any != 0.f) lv[l].cl.on = 0;
+      }
+      // a body: the pattern holds on most planes — find the planes where it does not (z-split smoother)
+      Level& v = lv[l];
+      if (!v.cl.on && !v.dist && v.g.D == 3 && wl::gsrb_fused_ok(v.x_, perdir, v.dist) && wl::gsrb_pair_geom_ok(v.x_) && v.cl.c[0] != 0.f) {
+        WL_TRY(wl::const_plane_range(v.L, v.x_, v.cl.c, &v.za, &v.zb, s));
+        const int m = 4, na = std::max(v.g.k0, v.za - m), nb = std::min(v.g.k1, v.zb + m + 1);
+        const int far = (na - v.g.k0) + (v.g.k1 - nb);
+        v.part = v.zb >= v.za && far >= 16 && far * 4 >= (v.g.k1 - v.g.k0) && v.x_.cs >= zsplit_min;     // worth it: at least a quarter of the planes are far
+        v.clp = v.cl; v.clp.on = 1;
       }
     }
   }
@@ -157,6 +168,35 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
   const bool fused = it == 4 && use_fused && (wl::gsrb_fused_ok(p.x_, perdir, p.dist) || pair_slab(p));
   if (p.pend && !fused) WL_TRY(flush_pending(l, w, s));
   ProfScope ps(l == 0 ? WL_PROF_SMOOTH : -1, s);   // only the finest level is a named slot
+  if (fused && p.part && use_zsplit && !p.dist) {
+    // Level with a body: the blocked kernels take plane sub-ranges (k0/k1 of the grid they are given only delimit the planes a launch
+    // outputs; inputs are read across the cut, outputs are separate arrays).  Planes at least 4 away from the body run the
+    // constant-coefficient pair kernels, the others the general kernels — the same bits either way.
+    const int m = 4, na = std::max(p.g.k0, p.za - m), nb = std::min(p.g.k1, p.zb + m + 1);
+    auto sub = [&](int a, int b) { GridX g = p.x_; g.k0 = a; g.k1 = b; return g; };
+    struct Part { int a, b; const wl::ConstL* cl; } parts[3] = {{na, nb, &p.cl}, {p.g.k0, na, &p.clp}, {nb, p.g.k1, &p.clp}};
+    const bool pro = p.pend;
+    Level& coarse = lv[(size_t)(pro ? l + 1 : l)];
+    p.pend = false;
+    {
+      ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s);
+      for (int i = 0; i < 3; i++) if (parts[i].b > parts[i].a) {
+        const GridX g = sub(parts[i].a, parts[i].b);
+        if (pro) WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, g, coarse.x_, w, *parts[i].cl, s));
+        else WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, g, *parts[i].cl, s));
+      }
+    }
+    {
+      ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s);
+      for (int i = 0; i < 3; i++) if (parts[i].b > parts[i].a) {
+        const GridX g = sub(parts[i].a, parts[i].b);
+        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nullptr, 2, 1, *parts[i].cl, s));
+        else WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, g, w, nullptr, 2, 1, *parts[i].cl, s));
+      }
+    }
+    if (!pro) std::swap(p.r, p.rs);
+    return 0;        // (the norms of the new residual are left to the caller: norms_done stays false)
+  }
   if (fused) {   // two z-marching kernels instead of six passes (+ the pending prolongation as an extra stage of kernel A)
     const RedWs* nws = want_norms ? &ws : nullptr;
     if (p.pend) {
@@ -485,11 +525,12 @@ int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 
   if (l < 0 || l >= (int)mg->lv.size()) return -1;
   const wl_mg::Level& p = mg->lv[(size_t)l];
   if (mg->pair_slab(p)) return 2;
+  if (p.part && mg->use_zsplit && mg->use_fused && !p.dist) return 3;
   if (!(mg->use_fused && wl::gsrb_fused_ok(p.x_, mg->perdir, p.dist))) return 0;
   return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
 }
 int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
-int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; return 0; }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

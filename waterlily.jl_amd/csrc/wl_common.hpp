@@ -181,6 +181,7 @@ __device__ __forceinline__ float wl_cl_coef(int Ia, int Na, float c) { return (I
 __device__ __forceinline__ int wl_cl_cnt(int Ia, int Na) { return ((Ia <= 2 || Ia >= Na) ? 0 : 1) + ((Ia + 1 <= 2 || Ia + 1 >= Na) ? 0 : 1); }
 #endif
 int check_const_L(const float* L, const GridX& g, ConstL* out, int* dev_flag, hipStream_t s);
+int const_plane_range(const float* L, const GridX& g, const float* c, int* za, int* zb, hipStream_t s);
 int fill(float* a, float v, size_t n, hipStream_t s);
 int scale(float* a, float s_, size_t n, hipStream_t s);
 int div_scalar(float* a, float s_, size_t n, hipStream_t s);

@@ -68,6 +68,9 @@ __host__ __device__ inline int ztile_count(int nx, int ny, int H) {
   const int CX = ZT_X - 2 * H, CY = ZT_Y - 2 * H;
   return ((nx - 2 + CX - 1) / CX) * ((ny - 2 + CY - 1) / CY);
 }
+// plane K of the array is an interior plane of the grid (k0/k1 only delimit the planes a launch OUTPUTS: smooth! may hand a
+// sub-range of the planes to these kernels and the rest to the pair kernels of wl_fused2.hip)
+__device__ __forceinline__ bool pint1(const GridX& g, int K) { const int Kg = g.gk + K; return K >= 0 && K < g.nz && Kg >= 1 && Kg <= g.gnz - 2; }
 // may the cell (i,j,K) be updated by colour sweep k0?  colour rule + quirk Q4 exactly as k_gs_sweep (D==3)
 __device__ __forceinline__ bool gs_upd(const GridX& g, int i, int j, int K, int k0) {
   return (((i + j + K + 3 + k0) & 1) != 0) && !(K + 1 > 2 * (g.gnz / 2) - 1);
@@ -134,7 +137,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
     const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
     const long o0 = t.oc + (long)K * g.sz;
     n_r0 = pl0 ? r[o0] : 0.f;
-    const bool pll = t.inter && K >= g.k0 && K < g.k1;           // interior cell of plane K: its six face coefficients
+    const bool pll = t.inter && pint1(g, K);           // interior cell of plane K: its six face coefficients
     if (CL) {
       n_lz0 = pl0 ? cl_coef(g.gk + K + 1, g.gnz, cl.c[2]) : 0.f;
       n_lx = pll ? kx : 0.f; n_lxp = pll ? kxp : 0.f; n_ly = pll ? ky : 0.f; n_lyp = pll ? kyp : 0.f;
@@ -153,7 +156,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
     r0 = n_r0; lz0 = n_lz0; lx0 = n_lx; lxp0 = n_lxp; ly0 = n_ly; lyp0 = n_lyp;
     const float lzp0 = n_lzp;
     const long o0 = t.oc + (long)K * g.sz;
-    const bool pl = t.inter && K >= g.k0 && K < g.k1;
+    const bool pl = t.inter && pint1(g, K);
     const float dg0 = pl ? diag6(lx0, lxp0, ly0, lyp0, lz0, lzp0) : 0.f;     // D[I]   (ghost cells: stored D is 0)
     d0 = inv_diag(dg0);                                                      // iD[I]
     if (PRO && pl) {   // increment!(fine;ω) with ϵ = x_c[down(I)]          src/Poisson.jl:100-104, mult :70-76
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
       if (t.core && K >= t.ks && K < t.ke) { pa.rnew[o0] = r0; pa.x[o0] = pa.x[o0] + pa.w * ep; }
     }
     if (K < Kend) fetch(K + 1);
-    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const bool pl1 = t.inter && pint1(g, K - 1);
     e0 = r0 * d0;                                                   // ϵ = r·iD   :142 (ghost cells: 0·0)
     __syncthreads();                                                // LDS of the previous step is complete
     const int pb = (K - 1) & 1, cb = K & 1;
@@ -176,7 +179,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_A(GridX g, float* __restrict__
     if (pl1 && (K - 1) >= t.ks - 1 && gs_upd(g, t.i, t.j, g.gk + K - 1, 1))
       e1 = gs_val(r1, d1, sA[pb][t.li - 1], sA[pb][t.li + 1], sA[pb][t.li - ZT_X], sA[pb][t.li + ZT_X], e2, e0, lx1, lxp1, ly1, lyp1, lz1, lz0);
     // ---- sweep 2 on plane K-2 (x-y neighbours: plane K-2 after sweep 1, written one step ago)
-    const bool pl2 = t.inter && (K - 2) >= g.k0 && (K - 2) < g.k1;
+    const bool pl2 = t.inter && pint1(g, K - 2);
     if (pl2 && (K - 2) >= t.ks && gs_upd(g, t.i, t.j, g.gk + K - 2, 2))
       e2 = gs_val(r2, d2, sB[pb][t.li - 1], sB[pb][t.li + 1], sB[pb][t.li - ZT_X], sB[pb][t.li + ZT_X], e3, e1, lx2, lxp2, ly2, lyp2, lz2, lz1);
     sA[cb][t.li] = e0;
@@ -212,7 +215,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__
     const bool pl0 = t.indom && K >= 0 && K <= g.nz - 1;
     const long o0 = t.oc + (long)K * g.sz;
     n_e0 = pl0 ? emid[o0] : 0.f;
-    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const bool pl1 = t.inter && pint1(g, K - 1);
     const long o1 = o0 - g.sz;
     n_r1 = pl1 ? r[o1] : 0.f;
     if (CL) {
@@ -232,7 +235,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__
     e0 = n_e0; lz0 = n_lz0; r1 = n_r1; lx1 = n_lx1; lxp1 = n_lxp1; ly1 = n_ly1; lyp1 = n_lyp1;
     const float x3 = n_x3;
     if (K < Kend) fetch(K + 1);
-    const bool pl1 = t.inter && (K - 1) >= g.k0 && (K - 1) < g.k1;
+    const bool pl1 = t.inter && pint1(g, K - 1);
     dg1 = pl1 ? diag6(lx1, lxp1, ly1, lyp1, lz1, lz0) : 0.f;        // D of plane K-1 (its Lz[I+δz] is plane K's Lz)
     d1 = inv_diag(dg1);
     const bool pl3 = t.core && (K - 3) >= t.ks && (K - 3) < t.ke;
@@ -243,7 +246,7 @@ __global__ void __launch_bounds__(ZT_N, 8) k_gsrb_B(GridX g, float* __restrict__
     if (pl1 && (K - 1) >= t.ks - 2 && gs_upd(g, t.i, t.j, g.gk + K - 1, 3))
       e1 = gs_val(r1, d1, sA[pb][t.li - 1], sA[pb][t.li + 1], sA[pb][t.li - ZT_X], sA[pb][t.li + ZT_X], e2, e0, lx1, lxp1, ly1, lyp1, lz1, lz0);
     // ---- sweep 4 on plane K-2
-    const bool pl2 = t.inter && (K - 2) >= g.k0 && (K - 2) < g.k1;
+    const bool pl2 = t.inter && pint1(g, K - 2);
     if (pl2 && (K - 2) >= t.ks - 1 && gs_upd(g, t.i, t.j, g.gk + K - 2, 4))
       e2 = gs_val(r2, d2, sB[pb][t.li - 1], sB[pb][t.li + 1], sB[pb][t.li - ZT_X], sB[pb][t.li + ZT_X], e3, e1, lx2, lxp2, ly2, lyp2, lz2, lz1);
     // ---- increment! on plane K-3: r' = r − ω·Aϵ ; x += ω·ϵ          src/Poisson.jl:100-104, mult :70-76

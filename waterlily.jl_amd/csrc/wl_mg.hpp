@@ -10,6 +10,8 @@ struct wl_mg {
     float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
     float *em = nullptr, *rs = nullptr;   // scratch of the fused smoother: ϵ after sweep 2, new residual (ghosts stay zero)
     wl::ConstL cl{};                 // constant-coefficient level (verified at update!)
+    // body levels: the coefficients deviate from the constant pattern only on planes [za,zb]; smooth! runs the pair kernels on the other planes
+    bool part = false; int za = 0, zb = -1; wl::ConstL clp{};
     bool pend = false;       // the V-cycle's prolongate!+increment! of this level is deferred into the next smooth! (fused kernel A)
     bool dist = false;       // z-slab distributed level (halo exchanges) vs replicated on every rank
     GridX view;              // replicated level fed by a distributed parent: the planes of the full array this rank computes
@@ -22,6 +24,8 @@ struct wl_mg {
   bool use_constl = true;   // allow the constant-coefficient specialisations where the pattern is verified
   bool store_eps = true;    // the blocked smoother also stores the final ϵ (p.ϵ of the reference); the mom_step! composite turns it off
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
+  bool use_zsplit = true;   // body levels: constant-coefficient pair kernels on the planes away from the body, general kernels on the rest
+  long zsplit_min = 32L << 20;   // ... on levels of at least this many cells (smaller ranges do not fill 256 CUs: 256³ loses 4 %, 384³ gains 4 %, 512³ 7 %)
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
   bool tail_ok(int first) const;
   int tail(int first, float w, hipStream_t s);

@@ -3,6 +3,8 @@
 // x-y plane (coalesced, ghosts masked), pz walks z planes.  Arithmetic order follows the
 // reference statement by statement (compiled with -ffp-contract=off) so that element-wise results
 // are bit-identical to the CPU restatement; only reductions differ in association order.
+#include <vector>
+
 #include "wl_common.hpp"
 
 namespace {
@@ -263,6 +265,19 @@ __global__ void k_pcg(GridX g, float* __restrict__ eps, float* __restrict__ r, f
     }
   }
   if (STAGE != 3) { acc = block_sum(acc); if (threadIdx.x == 0) part[blockIdx.x] = acc; }
+}
+// per-plane version of the test above: bad[k] = 1 if plane k holds a cell whose coefficients deviate from the constant pattern
+template <int D>
+__global__ void k_plane_bad(GridX g, const float* __restrict__ L, float c0, float c1, float c2, unsigned char* __restrict__ bad) {
+  int i, j; long m; int pz;
+  wl_tile(g, m, pz);
+  if (!cell_ij(g, m, i, j)) return;
+  const int k = pz;
+  const long o = m + (long)k * g.sz;
+  const float c[3] = {c0, c1, c2};
+  const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
+  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 1};
+  for (int a = 0; a < D; a++) if (L[(long)a * g.cs + o] != ((I[a] <= 2 || I[a] >= N[a]) ? 0.f : c[a])) bad[k] = 1;
 }
 // deterministic second stage: res_d[slot] = Σ partials
 __global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
@@ -731,8 +746,9 @@ int check_const_L(const float* L, const GridX& g, ConstL* out, int* dev_flag, hi
   int bad = 1;
   WL_HIP(hipMemcpyAsync(&bad, dev_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   WL_HIP(hipStreamSynchronize(s));
-  if (!bad) {
-    out->on = 1; for (int a = 0; a < 3; a++) out->c[a] = c[a];
+  for (int a = 0; a < 3; a++) out->c[a] = c[a];       // (the sampled constants and their tables are returned even when the test fails:
+  {                                                   //  smooth! may still use them on the planes that const_plane_range finds clean)
+    out->on = bad ? 0 : 1;
     for (int nz = 0; nz < 3; nz++) for (int ny = 0; ny < 3; ny++) for (int nx = 0; nx < 3; nx++) {
       // pair sums lower+upper face: 2 non-wall faces c+c, one c+0 (or 0+c: same value), none 0+0
       const float px = nx == 2 ? c[0] + c[0] : (nx == 1 ? c[0] + 0.f : 0.f), py = ny == 2 ? c[1] + c[1] : (ny == 1 ? c[1] + 0.f : 0.f);
@@ -741,6 +757,21 @@ int check_const_L(const float* L, const GridX& g, ConstL* out, int* dev_flag, hi
       out->Dt[nx + 3 * ny + 9 * nz] = d; out->iDt[nx + 3 * ny + 9 * nz] = (d == 0.f) ? d : 1.0f / d;
     }
   }
+  return 0;
+}
+// planes [za,zb] (inclusive, local indices) outside which every coefficient of L follows the constant pattern with constants c;
+// za > zb: none deviates.  Host-synchronising (update! time only).  Single domain, 3-D.
+int const_plane_range(const float* L, const GridX& g, const float* c, int* za, int* zb, hipStream_t s) {
+  unsigned char* d = nullptr;
+  WL_HIP(hipMalloc((void**)&d, (size_t)g.nz));
+  WL_HIP(hipMemsetAsync(d, 0, (size_t)g.nz, s));
+  DSEL(g.D, k_plane_bad, wl_plane_grid(g, g.nz), dim3(WL_BLOCK), 0, s, g, L, c[0], c[1], c[2], d);
+  std::vector<unsigned char> h((size_t)g.nz);
+  WL_HIP(hipMemcpyAsync(h.data(), d, h.size(), hipMemcpyDeviceToHost, s));
+  WL_HIP(hipStreamSynchronize(s));
+  (void)hipFree(d);
+  *za = g.nz; *zb = -1;
+  for (int k = 0; k < g.nz; k++) if (h[(size_t)k]) { if (k < *za) *za = k; if (k > *zb) *zb = k; }
   return 0;
 }
 int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s) {

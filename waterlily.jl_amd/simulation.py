@@ -188,7 +188,8 @@ class FusedSimulation:
         return [bool(lib().wl_mg_level_is_const(mg, l)) for l in range(self.nlevels())]
 
     def smoother_kinds(self):
-        """per level: 0 one kernel per pass, 1 temporally blocked smoother, 2 blocked pair kernels (constant coefficients)"""
+        """per level: 0 one kernel per pass, 1 temporally blocked smoother, 2 blocked pair kernels (constant coefficients),
+        3 z-split (pair kernels on the planes away from the body, general blocked kernels around it)"""
         mg = lib().wl_sim_pois(self._h)
         return [int(lib().wl_mg_smoother_kind(mg, l)) for l in range(self.nlevels())]
 
