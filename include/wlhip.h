@@ -212,6 +212,8 @@ int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_se
 int wl_comm_destroy(wl_comm* c);
 int wl_comm_rank(const wl_comm* c);
 int wl_comm_size(const wl_comm* c);
+/* counters since creation: {halo exchanges, bytes this rank sent in them, scalar combines (all-gather of 128 B), plane all-gathers} */
+int wl_comm_stats(const wl_comm* c, int64_t out4[4]);
 /* exchange `depth` z-planes of an (ncomp)-component field with both neighbours (test hook; the composites call it internally) */
 int wl_halo_exchange(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* stream);
 /* in-place all-gather of the planes [view->k0,view->k1) each rank computed of a replicated (full) array (test hook) */

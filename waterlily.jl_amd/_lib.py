@@ -107,6 +107,7 @@ SIGNATURES = {
     "wl_comm_destroy": (i32, [P]),
     "wl_comm_rank": (i32, [P]),
     "wl_comm_size": (i32, [P]),
+    "wl_comm_stats": (i32, [P, C.POINTER(C.c_int64)]),
     "wl_halo_exchange": (i32, [P, P, G, i32, i32, P]),
     "wl_allgather_planes": (i32, [P, P, G, i32, P]),
     "wl_grid_slab": (i32, [G, i32, C.POINTER(C.c_int32), i32, i32, i32]),

@@ -109,6 +109,7 @@ int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t
   const bool has_lo = (g.gk + g.k0 > 1), has_hi = (g.gk + g.k1 < g.gnz - 1);
   const size_t bytes = (size_t)depth * (size_t)g.sz * sizeof(float);
   if (g.k1 - g.k0 < depth || g.k0 < depth) { wl_set_error("halo deeper than the slab"); return WL_EINVAL; }
+  c->n_halo++; c->halo_bytes += (long)bytes * ncomp * ((has_lo ? 1 : 0) + (has_hi ? 1 : 0));
   WL_TRY(c->group_begin());
   for (int q = 0; q < ncomp; q++) {
     float* b = a + (size_t)q * g.cs;
@@ -135,6 +136,7 @@ int halo_async_wait(wl_comm* c, hipStream_t compute) {
 int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s) {
   if (!c || c->size == 1) return 0;
   WL_TRY(c->ensure_scratch());
+  c->n_combine++;
   // res_d (64 B) and res_f (32 B at +64) are adjacent: one 128-byte record per rank
   WL_TRY(c->allgather(ws.res_d, c->gather, 128, s));
   hipLaunchKernelGGL(k_combine, dim3(1), dim3(64), 0, s, (const char*)c->gather, c->size, ws.res_d, ws.res_f);
@@ -143,6 +145,7 @@ int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s) {
 int allgather_planes(wl_comm* c, float* a, const GridX& view, int ncomp, hipStream_t s) {
   if (!c || c->size == 1) return 0;
   const size_t block = (size_t)(view.k1 - view.k0) * (size_t)view.sz;       // floats per rank
+  c->n_gather += ncomp;
   for (int q = 0; q < ncomp; q++) {
     float* base = a + (size_t)q * view.cs + (size_t)view.sz;                  // first interior plane of the full array
     WL_TRY(c->allgather(base + (size_t)c->rank * block, base, block * sizeof(float), s));
@@ -176,6 +179,10 @@ int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_se
 int wl_comm_destroy(wl_comm* c) { delete c; return 0; }
 int wl_comm_rank(const wl_comm* c) { return c ? c->rank : 0; }
 int wl_comm_size(const wl_comm* c) { return c ? c->size : 1; }
+int wl_comm_stats(const wl_comm* c, int64_t out[4]) {
+  out[0] = c ? c->n_halo : 0; out[1] = c ? c->halo_bytes : 0; out[2] = c ? c->n_combine : 0; out[3] = c ? c->n_gather : 0;
+  return 0;
+}
 int wl_halo_exchange(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* st) {
   WL_CHECK(g && g->D == 3, "halo exchange needs a 3-D slab grid");
   return wl::halo(c, a, gx(*g), ncomp, depth, wl_stream(st));

@@ -12,6 +12,8 @@ struct wl_comm {
   virtual int group_begin() { return 0; }
   virtual int group_end() { return 0; }
   int ensure_scratch();
+  // counters since creation (wl_comm_stats): halo exchanges, bytes this rank sent in them, scalar combines, plane all-gathers
+  long n_halo = 0, halo_bytes = 0, n_combine = 0, n_gather = 0;
   // second HIP stream for halo exchanges that overlap interior stencil work (+ the two events that order it with the compute stream)
   hipStream_t cs = nullptr; hipEvent_t ev_ready = nullptr, ev_done = nullptr;
   int ensure_async();

@@ -207,6 +207,13 @@ class SlabSimulation:
         return full
 
 
+def comm_stats(comm):
+    """{halo exchanges, bytes sent in them by this rank, scalar combines, plane all-gathers} since the communicator was created"""
+    out = (C.c_int64 * 4)()
+    check(lib().wl_comm_stats(comm.handle, out))
+    return {"halo_exchanges": int(out[0]), "halo_bytes_sent": int(out[1]), "scalar_combines": int(out[2]), "plane_allgathers": int(out[3])}
+
+
 def make_comm(dist, device, prefer="rccl"):
     """RCCL transport when the process group is nccl(=RCCL); if creating it fails on ANY rank, every rank falls back
     (decided by an all-reduce, so nobody is left waiting) to the host-staged callback transport over a gloo group."""
@@ -246,12 +253,14 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
         check(lib().wl_prof_enable(1))          # HIP-event pairs around rank 0's finest-level smoother kernels
     dist.barrier()
     torch.cuda.synchronize()
+    cs0 = comm_stats(comm)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sim.mom_step_()
     torch.cuda.synchronize()
     dist.barrier()
     el = time.perf_counter() - t0
+    cs1 = comm_stats(comm)
     t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
@@ -274,7 +283,8 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false, {world} z-slabs",
                           "size": N, "parallelism": f"zslab{world}", "transport": type(comm).__name__, "mean_pois_n": float(sum(pn)) / max(1, len(pn)),
-                          "dt_last": float(sim.dt[-1])},
+                          "dt_last": float(sim.dt[-1]),
+                          "comm_per_step_rank0": {k: (cs1[k] - cs0[k]) / args.steps for k in cs1}},
                "roofline": roof, "cpu_baseline": None}
         print(json.dumps(out), flush=True)
     dist.barrier()
