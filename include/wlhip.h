@@ -192,6 +192,19 @@ int wl_sim_phase(wl_sim* s, int phase, void* stream);
 int wl_sim_apply_ic(wl_sim* s, int kind, void* stream);
 /* measure!(flow, sphere(c,R); ϵ): closed-form AutoBody sphere/circle (src/Body.jl:28-51, src/AutoBody.jl:29-37) */
 int wl_sim_measure_sphere(wl_sim* s, const float* host_center, float R, float eps, void* stream);
+/* Closed-form AutoBody shapes (src/AutoBody.jl:21,29-37 with the gradient of the sdf written out; arbitrary Julia sdf/map closures
+ * cannot cross a C ABI).  WL_BODY_SPHERE: sdf = |m∘(x−c)|−R — m = (1,1,1) the sphere/circle, an axis with m = 0 is dropped: the
+ * cylinder along that axis.  WL_BODY_PLANE: sdf = m·(x−c), m the (not necessarily unit) normal pointing into the fluid.
+ * A translating body map(x,t) = x − V·t: the caller passes the current c and V, measure! stores V in flow.V (AutoBody.jl:36-37). */
+enum { WL_BODY_SPHERE = 1, WL_BODY_PLANE = 2 };
+typedef struct wl_body { int32_t kind; float c[3]; float R; float m[3]; float V[3]; } wl_body;
+/* the same on the caller's arrays — what measure!(a::Flow,body), pressure_force(sim), viscous_force(sim) bind for a closed-form body */
+int wl_measure_body(float* sigma, float* mu0, float* mu1, float* V, const wl_grid* g, const wl_body* host_body, float eps, int exitBC, uint32_t perdir_mask, void* stream);
+int wl_pressure_force_body(const float* p, const wl_grid* g, const wl_body* host_body, double out[3], void* stream);
+int wl_viscous_force_body(const float* u, const wl_grid* g, float nu, const wl_body* host_body, double out[3], void* stream);
+int wl_sim_measure_body(wl_sim* s, const wl_body* host_body, float eps, void* stream);          /* measure! + update!(pois) */
+int wl_sim_pressure_force_body(wl_sim* s, const wl_body* host_body, double out[3], void* stream); /* src/Metrics.jl:116-133 */
+int wl_sim_viscous_force_body(wl_sim* s, const wl_body* host_body, double out[3], void* stream);  /* src/Metrics.jl:140-154 */
 /* pressure_force(sim) for that sphere (src/Metrics.jl:116-133): Float64 accumulation, does not touch flow.f */
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* host_center, float R, double* host_out, void* stream);
 int wl_sim_viscous_force_sphere(wl_sim* s, const float* center, float R, double* out, void* stream);   /* viscous_force(sim) src/Metrics.jl:140-154 (single domain) */

@@ -91,6 +91,10 @@ def lib(omp=False):
         ("wlo_sim_step", None, [C.c_void_p, C.c_int]),
         ("wlo_sim_step_until", C.c_int, [C.c_void_p, dbl, C.c_int, C.c_int]),
         ("wlo_sim_measure", None, [C.c_void_p]),
+        ("wlo_sim_set_body", None, [C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
+        ("wlo_body_measure", None, [C.c_int, C.c_int, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p, C.c_void_p, dbl, C.c_void_p]),
+        ("wlo_pressure_force_body", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
+        ("wlo_viscous_force_body", None, [C.c_int, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
         ("wlo_sim_time", dbl, [C.c_void_p]),
         ("wlo_sim_flow_time", dbl, [C.c_void_p]),
         ("wlo_sim_dt", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -307,6 +311,46 @@ def viscous_force(u, nu, df, center, R):
     return np.array(list(out))
 
 
+def _body(body, D):
+    """("sphere", c, R) | ("cylinder", c, R, axis) — axis (0-based) is the direction the cylinder extends along | ("plane", point, normal)
+    [+ optional trailing translation velocity] -> (kind, c, R, m, vel) for the C API"""
+    name = body[0]
+    if name == "sphere":
+        kind, c, R, m, rest = 1, body[1], float(body[2]), [1.0] * D, body[3:]
+    elif name == "cylinder":
+        kind, c, R, m, rest = 1, body[1], float(body[2]), [0.0 if k == int(body[3]) else 1.0 for k in range(D)], body[4:]
+    elif name == "plane":
+        kind, c, R, m, rest = 2, body[1], 0.0, [float(v) for v in body[2]], body[3:]
+    else:
+        raise ValueError(name)
+    vel = [float(v) for v in rest[0]] if rest else [0.0] * D
+    return kind, _dbls(c), R, _dbls(m), _dbls(vel)
+
+
+def body_measure(body, x, fastd2=float("inf"), T=np.float64):
+    """measure(body,x,t;fastd²) -> (d, n, V)   src/AutoBody.jl:29-37"""
+    D = len(x)
+    kind, c, R, m, vel = _body(body, D)
+    out = (C.c_double * (1 + 2 * D))()
+    lib().wlo_body_measure(_tag(T), D, kind, c, R, m, vel, _dbls(x), float(fastd2), out)
+    return out[0], np.array(out[1:1 + D]), np.array(out[1 + D:1 + 2 * D])
+
+
+def pressure_force_body(p, df, body):
+    kind, c, R, m, _ = _body(body, p.ndim)
+    out = (C.c_double * p.ndim)()
+    lib().wlo_pressure_force_body(_dt(p), p.ndim, _ptr(p), _ptr(df), _ints(p.shape), kind, c, R, m, out)
+    return np.array(list(out))
+
+
+def viscous_force_body(u, nu, df, body):
+    D = u.ndim - 1
+    kind, c, R, m, _ = _body(body, D)
+    out = (C.c_double * D)()
+    lib().wlo_viscous_force_body(_dt(u), D, _ptr(u), float(nu), _ptr(df), _ints(u.shape[:D]), kind, c, R, m, out)
+    return np.array(list(out))
+
+
 def _view(ptr, shape, dtype):
     n = int(np.prod(shape))
     buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
@@ -440,13 +484,15 @@ class Simulation:
         self._keep += [ufn, dufn, gfn, icfn]
         kind, c, R = 0, None, 0.0
         if body is not None:
-            assert body[0] == "sphere"
-            kind, c, R = 1, _dbls(body[1]), float(body[2])
+            kind, c, R, bm, bvel = _body(body, D)
         self.U, self.L, self.nu = float(U), float(L), float(nu)
         self.h = self._lib.wlo_sim_create(_tag(T), D, _ints(dims), Uarr, ufn, dufn, float(L), float(U), float(dt), float(nu), float(eps),
                                           perdir_mask(perdir), int(exitBC), scheme, icfn, kind, c, R, gfn, None)
         if not self.h:
             raise AssertionError(self._lib.wlo_last_error().decode())
+        if body is not None and (body[0] != "sphere" or len(body) > 3):
+            self.set_body(body)      # the constructor's measure! only knows the sphere: redo it with the full description
+            self.measure()
 
     def __del__(self):
         if getattr(self, "h", None):
@@ -471,6 +517,11 @@ class Simulation:
 
     def phase(self, k):
         self._lib.wlo_sim_phase(self.h, k)
+
+    def set_body(self, body):
+        """replace the body (e.g. its new position and velocity); follow with measure() or step(remeasure=True)"""
+        kind, c, R, m, vel = _body(body, self.D)
+        self._lib.wlo_sim_set_body(self.h, kind, c, R, m, vel)
 
     def measure(self):
         self._lib.wlo_sim_measure(self.h)

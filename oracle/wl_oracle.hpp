@@ -627,28 +627,39 @@ template <class T> inline T mu0(T d, T e) { return d / e < -1 + std::sqrt(eps_at
 template <class T> inline T mu1(T d, T e) { return e * kern1<T>(std::min(std::max(d / e, (T)-1), (T)1)); }                             // Body.jl:60
 
 template <class T, int D>
-struct Body {  // kind 0: NoBody (Body.jl:81-83); kind 1: AutoBody(sdf = |x-c|-R) with identity map
+struct Body {  // kind 0: NoBody (Body.jl:81-83); kind 1: AutoBody(sdf = |m∘(x−c)|−R) — sphere / circle, or with an axis masked out
+               // (m=0) the cylinder along that axis; kind 2: AutoBody(sdf = m·(x−c)), a plane with (not necessarily unit) normal m.
+               // map(x,t) = x − vel·t is folded into c by the caller; its time derivative gives the body velocity vel (AutoBody.jl:36-37)
   int kind = 0;
   T c[D] = {};
   T R = 0;
-  // measure(body,x,t;fastd²)  — AutoBody.jl:29-37 in closed form for the sphere sdf
+  T m[D];
+  T vel[D] = {};
+  Body() { for (int k = 0; k < D; k++) m[k] = 1; }
+  // sdf(body,x,t) — AutoBody.jl:21
+  T sdf(const T* x) const {
+    if (kind == 0) return std::numeric_limits<T>::infinity();
+    T s = 0;
+    if (kind == 2) { for (int k = 0; k < D; k++) s += m[k] * (x[k] - c[k]); return s; }
+    for (int k = 0; k < D; k++) { const T dx = m[k] * (x[k] - c[k]); s += dx * dx; }
+    return std::sqrt(s) - R;
+  }
+  // measure(body,x,t;fastd²)  — AutoBody.jl:29-37 with the gradient of the sdf in closed form
   void measure(const T* x, T fastd2, T& d, T* nrm, T* Vb) const {
     for (int k = 0; k < D; k++) { nrm[k] = 0; Vb[k] = 0; }
     if (kind == 0) { d = std::numeric_limits<T>::infinity(); return; }
-    T s = 0; for (int k = 0; k < D; k++) s += (x[k] - c[k]) * (x[k] - c[k]);
-    T rr = std::sqrt(s);
-    d = rr - R;
+    T rr = 0;
+    if (kind == 2) d = sdf(x);
+    else { T s = 0; for (int k = 0; k < D; k++) { const T dx = m[k] * (x[k] - c[k]); s += dx * dx; } rr = std::sqrt(s); d = rr - R; }
     if (d * d > fastd2) return;                                                                 // :31
     T g[D]; bool nan = false;
-    for (int k = 0; k < D; k++) { g[k] = (x[k] - c[k]) / rr; if (std::isnan(g[k])) nan = true; }  // gradient of the sdf :32
+    if (kind == 2) { for (int k = 0; k < D; k++) g[k] = m[k]; }
+    else { for (int k = 0; k < D; k++) g[k] = (m[k] * (x[k] - c[k])) / rr; }                     // gradient of the sdf :32
+    for (int k = 0; k < D; k++) if (std::isnan(g[k])) nan = true;
     if (nan) return;                                                                            // :33
-    T m = 0; for (int k = 0; k < D; k++) m += g[k] * g[k];                                       // J = I  :34-35
-    m = std::sqrt(m); d /= m; for (int k = 0; k < D; k++) nrm[k] = g[k] / m;
-  }
-  T sdf(const T* x) const {  // sdf(body,x,t) — AutoBody.jl:21
-    if (kind == 0) return std::numeric_limits<T>::infinity();
-    T s = 0; for (int k = 0; k < D; k++) s += (x[k] - c[k]) * (x[k] - c[k]);
-    return std::sqrt(s) - R;
+    T mm = 0; for (int k = 0; k < D; k++) mm += g[k] * g[k];                                     // pseudo-sdf :34-35
+    mm = std::sqrt(mm); d /= mm; for (int k = 0; k < D; k++) nrm[k] = g[k] / mm;
+    for (int k = 0; k < D; k++) Vb[k] = vel[k];                                                 // −J\ṁ with J = I, ṁ = −vel :36-37
   }
 };
 

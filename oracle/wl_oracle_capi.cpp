@@ -2,6 +2,8 @@
 // restatement so tests/bench can drive it from Python ctypes.  dtype: 0 = Float32, 1 = Float64.
 #include "wl_oracle.hpp"
 
+#include <cmath>
+#include <limits>
 #include <string>
 #ifdef WLO_OMP
 #include <omp.h>
@@ -31,6 +33,14 @@ template <class T, int D> static UBC<T, D> mkU(const double* U, bc_fn_t fn, bc_f
 static PerDir mkP(unsigned m) { PerDir p; p.mask = m; return p; }
 
 struct Handle { int dtype, D; void* obj; };
+
+// general analytic body: kind 1 |m∘(x−c)|−R, kind 2 m·(x−c); vel = translation velocity (may be NULL)
+template <class T, int DD>
+static Body<T, DD> mkBody(int kind, const double* c, double R, const double* m, const double* vel) {
+  Body<T, DD> b; b.kind = kind; b.R = (T)R;
+  for (int d = 0; d < DD; d++) { b.c[d] = c ? (T)c[d] : (T)0; if (m) b.m[d] = (T)m[d]; if (vel) b.vel[d] = (T)vel[d]; }
+  return b;
+}
 
 extern "C" {
 
@@ -141,6 +151,22 @@ void wlo_pressure_force(int dtype, int D, void* p, void* df, const int* dims, co
 // viscous_force(u,ν,df,body)   body = sphere(c,R)
 void wlo_viscous_force(int dtype, int D, void* u, double nu, void* df, const int* dims, const double* c, double R, double* out) {
   DISPATCH(dtype, D, { Body<T, DD> b; b.kind = 1; for (int d = 0; d < DD; d++) b.c[d] = (T)c[d]; b.R = (T)R; viscous_force<T, DD>(mkV<T, DD>(u, dims), (T)nu, mkV<T, DD>(df, dims), b, out); });
+}
+
+// measure(body,x,t;fastd²) at one point: out = {d, n[D], V[D]} (as doubles)
+void wlo_body_measure(int dtype, int D, int kind, const double* c, double R, const double* m, const double* vel, const double* x, double fastd2, double* out) {
+  DISPATCH(dtype, D, {
+    Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, vel);
+    T xx[DD], d, n[DD], V[DD]; for (int k = 0; k < DD; k++) xx[k] = (T)x[k];
+    b.measure(xx, std::isinf(fastd2) ? std::numeric_limits<T>::infinity() : (T)fastd2, d, n, V);
+    out[0] = (double)d; for (int k = 0; k < DD; k++) { out[1 + k] = (double)n[k]; out[1 + DD + k] = (double)V[k]; }
+  });
+}
+void wlo_pressure_force_body(int dtype, int D, void* p, void* df, const int* dims, int kind, const double* c, double R, const double* m, double* out) {
+  DISPATCH(dtype, D, { Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, nullptr); pressure_force<T, DD>(mkS<T, DD>(p, dims), mkV<T, DD>(df, dims), b, out); });
+}
+void wlo_viscous_force_body(int dtype, int D, void* u, double nu, void* df, const int* dims, int kind, const double* c, double R, const double* m, double* out) {
+  DISPATCH(dtype, D, { Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, nullptr); viscous_force<T, DD>(mkV<T, DD>(u, dims), (T)nu, mkV<T, DD>(df, dims), b, out); });
 }
 
 // ---- Poisson / MultiLevelPoisson handle (x,L,z alias the caller's arrays) ---------------------
@@ -257,6 +283,10 @@ void* wlo_sim_field(void* h, const char* name) {
 void wlo_sim_step(void* h, int remeasure) { SIM(h, sim->step(remeasure != 0)); }
 int wlo_sim_step_until(void* h, double t_end, int remeasure, int max_steps) { int n = 0; SIM(h, n = sim->step_until(t_end, remeasure != 0, max_steps)); return n; }
 void wlo_sim_measure(void* h) { SIM(h, sim->measure()); }
+// replace the simulation's body (a moving body: new centre and velocity), to be followed by wlo_sim_measure / a remeasuring step
+void wlo_sim_set_body(void* h, int kind, const double* c, double R, const double* m, const double* vel) {
+  SIM(h, (sim->body = mkBody<T, DD>(kind, c, R, m, vel)));
+}
 double wlo_sim_time(void* h) { double t = 0; SIM(h, t = sim->sim_time()); return t; }
 double wlo_sim_flow_time(void* h) { double t = 0; SIM(h, t = (double)sim->flow.time()); return t; }
 int wlo_sim_dt(void* h, double* out, int cap) { int n = 0; SIM(h, { n = (int)sim->flow.dt.size(); for (int k = 0; k < n && k < cap; k++) out[k] = (double)sim->flow.dt[(size_t)k]; }); return n; }

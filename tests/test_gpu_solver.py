@@ -664,3 +664,82 @@ def test_zsplit_smoother_on_body_levels_is_bit_identical(w, exitBC):
         res[zs] = (sim.field("u"), sim.field("p"), sim.pois_n)
     assert res[0][2] == res[1][2]
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
+BODIES_3D = [
+    ("cylinder", (11.0, 13.5, 0.0), 4.0, 2),                                   # along z: the circle of the reference's 2-D cases, extruded
+    ("cylinder", (0.0, 14.0, 12.5), 3.5, 0),                                   # along x
+    ("plane", (0.0, 5.0, 0.0), (0.0, 1.0, 0.0)),                                # a floor: solid below y = 5
+    ("plane", (16.0, 8.0, 0.0), (0.3, 1.0, 0.0)),                               # an inclined wall, normal not unit
+    ("sphere", (12.0, 15.0, 15.5), 4.0, (0.25, -0.125, 0.0)),                   # a translating sphere: V ≠ 0
+]
+
+
+@pytest.mark.parametrize("body", BODIES_3D, ids=lambda b: b[0] + str(len(b)))
+def test_closed_form_bodies_measure_steps_and_forces(w, oracle, body):
+    """row f1: measure! for the closed-form shapes beyond the sphere — cylinder (axis mask), plane, and a translating body whose
+    velocity lands in flow.V — then mom_step! with BDIM! on them and the force read-outs, against the oracle."""
+    N = 32
+    nu = 0.02
+    so = oracle.Simulation((N, N, N), (1, 0, 0), 8.0, U=1, nu=nu, body=body, T=np.float32)
+    sg = w.FusedSimulation((N, N, N), (1, 0, 0), 8.0, U=1, nu=nu, has_body=True)
+    sg.measure_body_(body, 1.0)
+    for name, tol in (("mu0", 2e-6), ("mu1", 2e-6), ("V", 0)):
+        assert np.abs(sg.field(name) - so.field(name)).max() <= tol, name
+    if len(body) > 3 and body[0] == "sphere":
+        assert np.abs(so.field("V")).max() == 0.25                             # the band around the body carries the body velocity
+    sg.set_field("mu0", so.field("mu0")); sg.set_field("mu1", so.field("mu1")); sg.update_()
+    for step in range(3):
+        so.step(remeasure=False); sg.mom_step_()
+        assert sg.pois_n == so.pois_n
+        assert np.abs(sg.field("u") - so.u).max() < 5e-5, step
+    fo, fg = so.pressure_force(), sg.pressure_force_body(body)
+    assert np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+    vo, vg = so.viscous_force(), sg.viscous_force_body(body)
+    assert np.allclose(vg, vo, rtol=2e-3, atol=2e-3 * max(np.abs(vo).max(), 1e-6))
+
+
+def test_moving_cylinder_remeasure_every_step(w, oracle):
+    """sim_step!(remeasure=true) with a body that moves: every step the host passes the new centre and the velocity, measure! and
+    update!(pois) run on device (src/WaterLily.jl:136-149) — positions, V, the step and pois.n follow the oracle."""
+    n = (48, 32)
+    R, Ub = 4.0, (0.5, 0.0)
+    c0 = np.array([12.0, 15.0])
+    so = oracle.Simulation(n, (0, 0), 2 * R, U=1, nu=0.05, body=("sphere", tuple(c0), R, Ub), T=np.float32)
+    sg = w.FusedSimulation(n, (0, 0), 2 * R, U=1, nu=0.05, has_body=True)
+    for step in range(5):
+        t = float(np.sum(so.dt[:-1]))
+        c = tuple(c0 + np.array(Ub) * t)
+        so.set_body(("sphere", c, R, Ub)); so.step(remeasure=True)
+        sg.measure_body_(("sphere", c, R, Ub), 1.0); sg.mom_step_()
+        assert np.abs(sg.field("V") - so.field("V")).max() == 0
+        assert np.abs(sg.field("mu0") - so.field("mu0")).max() < 2e-6
+        assert sg.pois_n[-2:] == so.pois_n[-2:]
+        assert np.abs(sg.field("u") - so.u).max() < 1e-4, step
+    assert np.abs(so.u[:, :, 0]).max() > 0.3                                    # the fluid was set in motion by the body
+
+
+@pytest.mark.parametrize("body", [("sphere", (11.0, 15.0, 15.5), 4.0), ("cylinder", (11.0, 13.5, 0.0), 4.0, 2), ("plane", (0.0, 5.0, 0.0), (0.0, 1.0, 0.0))],
+                         ids=["sphere", "cylinder", "plane"])
+def test_reference_orchestration_with_a_body(w, oracle, body):
+    """Simulation(…; body) over the leaf operations — measure!(flow,body) (wl_measure_body), update!(pois), mom_step! with the general
+    BDIM!, pressure_force / viscous_force (wl_*_force_body) on the caller's arrays: the calls a `measure!(::Flow{HipArray}, body)` method
+    makes.  Against the oracle, and the fused composite gives the same fields."""
+    N = 32
+    so = oracle.Simulation((N, N, N), (1, 0, 0), 8.0, U=1, nu=0.02, body=body, T=np.float32)
+    sl = w.Simulation((N, N, N), (1, 0, 0), 8.0, U=1, nu=0.02, body=body)
+    sf = w.FusedSimulation((N, N, N), (1, 0, 0), 8.0, U=1, nu=0.02, has_body=True)
+    sf.measure_body_(body, 1.0)
+    for name, tol in (("mu0", 2e-6), ("mu1", 2e-6), ("V", 0)):
+        a = w.to_host(getattr(sl.flow, name))
+        assert np.abs(a - so.field(name)).max() <= tol, name
+        assert np.array_equal(a, sf.field(name)), name
+    for step in range(3):
+        so.step(remeasure=True); sl.sim_step_(remeasure=True)
+        assert list(sl.pois.n) == so.pois_n
+        assert np.abs(w.to_host(sl.flow.u) - so.u).max() < 5e-5, step
+    fo = so.pressure_force()
+    assert np.allclose(sl.pressure_force(), fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+    vo = so.viscous_force()
+    assert np.allclose(sl.viscous_force(), vo, rtol=2e-3, atol=2e-3 * max(np.abs(vo).max(), 1e-6))
+    assert np.allclose(sl.total_force(), so.total_force(), rtol=2e-3, atol=2e-3 * np.abs(fo).max())

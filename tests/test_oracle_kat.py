@@ -331,3 +331,50 @@ def test_viscous_force_zero_and_symmetry(oracle):
         u[..., 0] = ax.reshape((1, N) + (1,) * (D - 2))
         f = oracle.viscous_force(u, 1.0, df, c, N / 4)
         assert np.abs(f).max() < 1e-3 * (N / 4) ** (D - 1)
+
+
+# ------------------------------------------------------------------ test/test_bodies.jl:6-7,15-18,42-43,51-56
+def test_autobody_measure_known_answers(oracle):
+    r2 = math.sqrt(2.0)
+    # NoBody: measure == (Inf, 0, 0)   (:6-7) — the Flow-level measure! is a no-op for it (src/Body.jl:83)
+    # circ(x,t) = |x| − 2; body1 = circ − t: at t the radius is 2+t
+    d, n, V = oracle.body_measure(("sphere", (0, 0), 2.0), (r2, r2))
+    assert abs(d) < 1e-12 and np.allclose(n, [math.sqrt(.5)] * 2) and np.allclose(V, 0)                   # :15
+    d, n, V = oracle.body_measure(("sphere", (0, 0, 0), 3.0), (2.0, 0.0, 0.0))
+    assert np.isclose(d, -1.0) and np.allclose(n, [1, 0, 0]) and np.allclose(V, 0)                         # :16  (t=1)
+    # body2 = AutoBody(circ, (x,t)->x.+t²): ξ = x − c with c = −t², body velocity −2t
+    d, n, V = oracle.body_measure(("sphere", (0, 0), 2.0, (0.0, 0.0)), (r2, r2))
+    assert abs(d) < 1e-12 and np.allclose(n, [math.sqrt(.5)] * 2) and np.allclose(V, 0)                   # :17  (t=0)
+    d, n, V = oracle.body_measure(("sphere", (-1, -1, -1), 2.0, (-2.0, -2.0, -2.0)), (1.0, -1.0, -1.0))
+    assert abs(d) < 1e-12 and np.allclose(n, [1, 0, 0]) and np.allclose(V, [-2, -2, -2])                   # :18  (t=1)
+    # fast version: outside fastd² only the distance is returned   (:42-43)
+    full = oracle.body_measure(("sphere", (0, 0), 2.0), (3.0, 4.0))
+    fast = oracle.body_measure(("sphere", (0, 0), 2.0), (3.0, 4.0), fastd2=9)
+    assert np.isclose(full[0], 3.0) and np.isclose(fast[0], 3.0) and np.allclose(full[1], fast[1]) and np.allclose(full[1], [0.6, 0.8])
+    cut = oracle.body_measure(("sphere", (0, 0), 2.0), (3.0, 4.0), fastd2=8)
+    assert np.isclose(cut[0], 3.0) and np.allclose(cut[1], 0) and np.allclose(cut[2], 0)
+    # RigidMap with a linear velocity (a rotation does not change the circle): (1/2, [1,0], [1,0])   (:51-56)
+    for T in (np.float32, np.float64):
+        d, n, V = oracle.body_measure(("sphere", (0, 0), 1.0, (1.0, 0.0)), (1.5, 0.0), T=T)
+        assert np.isclose(d, 0.5) and np.allclose(n, [1, 0]) and np.allclose(V, [1, 0])
+
+
+def test_cylinder_and_plane_bodies(oracle):
+    """closed-form shapes beyond the sphere: a cylinder is the circle sdf with one axis masked out, a plane is n·(x−c) with the
+    pseudo-sdf correction d/|∇f| (src/AutoBody.jl:34-35) — checked against their analytical distance / normal"""
+    d, n, V = oracle.body_measure(("cylinder", (1.0, 2.0, 7.0), 2.0, 2), (4.0, 6.0, -3.0))
+    assert np.isclose(d, 3.0) and np.allclose(n, [0.6, 0.8, 0.0])
+    d, n, V = oracle.body_measure(("cylinder", (1.0, 2.0, 7.0), 2.0, 0), (40.0, 2.0, 10.0))
+    assert np.isclose(d, 1.0) and np.allclose(n, [0, 0, 1])
+    d, n, V = oracle.body_measure(("plane", (0.0, 1.0, 0.0), (0.0, 2.0, 0.0), (0.0, 0.5, 0.0)), (3.0, 4.0, 5.0))
+    assert np.isclose(d, 3.0) and np.allclose(n, [0, 1, 0]) and np.allclose(V, [0, 0.5, 0])
+    d, n, V = oracle.body_measure(("plane", (0.0, 0.0), (3.0, 4.0)), (1.0, 1.0))
+    assert np.isclose(d, 7.0 / 5.0) and np.allclose(n, [0.6, 0.8])
+    # measure! of a wall y < 4 in a 2-D box: μ₀ of the y-faces ramps 0 → 1 across the plane, nothing varies along x, V = 0
+    sim = oracle.Simulation((16, 16), (1.0, 0.0), 16, nu=0.1, body=("plane", (0.0, 4.0), (0.0, 1.0)), T=np.float64)
+    mu0 = sim.field("mu0")
+    assert np.allclose(mu0[2:-2, :, 1], mu0[3:4, :, 1])          # (BC!(μ₀,0) only touches the boundary faces)
+    col = mu0[5, 1:-1, 1]
+    assert col[0] == 0 and col[-1] == 1 and np.all(np.diff(col) >= 0)
+    assert np.isclose(mu0[5, 5, 1], 0.5)          # 0-based index 5 = I 6: its lower y-face sits at y = 6 − 1.5 − ½ = 4 → d = 0 → μ₀ = ½
+    assert np.all(sim.field("V") == 0)

@@ -12,6 +12,31 @@ class wl_grid(C.Structure):
                 ("k0", C.c_int32), ("k1", C.c_int32), ("gk", C.c_int32), ("gnz", C.c_int32)]
 
 
+class wl_body(C.Structure):
+    """include/wlhip.h wl_body: closed-form AutoBody shapes"""
+    _fields_ = [("kind", C.c_int32), ("c", C.c_float * 3), ("R", C.c_float), ("m", C.c_float * 3), ("V", C.c_float * 3)]
+
+
+def make_body(body, D):
+    """("sphere", c, R) | ("cylinder", c, R, axis) — axis (0-based) is the direction the cylinder extends along |
+    ("plane", point, normal), each optionally followed by the body's translation velocity -> wl_body"""
+    name = body[0]
+    pad = lambda v: [float(x) for x in v] + [0.0] * (3 - len(v))   # noqa: E731
+    b = wl_body()
+    if name == "sphere":
+        b.kind, b.R, m, rest = 1, float(body[2]), [1.0] * D, body[3:]
+    elif name == "cylinder":
+        b.kind, b.R, m, rest = 1, float(body[2]), [0.0 if k == int(body[3]) else 1.0 for k in range(D)], body[4:]
+    elif name == "plane":
+        b.kind, b.R, m, rest = 2, 0.0, list(body[2]), body[3:]
+    else:
+        raise ValueError(f"unknown body {name!r}")
+    b.c = (C.c_float * 3)(*pad(list(body[1])))
+    b.m = (C.c_float * 3)(*pad(m))
+    b.V = (C.c_float * 3)(*pad(list(rest[0]) if rest else [0.0] * D))
+    return b
+
+
 class wl_sim_desc(C.Structure):
     _fields_ = [("D", C.c_int32), ("dims", C.c_int32 * 3), ("uBC", C.c_float * 3), ("nu", C.c_float), ("dt0", C.c_float),
                 ("perdir_mask", C.c_uint32), ("exitBC", C.c_int32), ("scheme", C.c_int32), ("has_body", C.c_int32),
@@ -115,6 +140,12 @@ SIGNATURES = {
     "wl_prof_enable": (i32, [i32]),
     "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),
     "wl_sim_pressure_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),
+    "wl_measure_body": (i32, [P, P, P, P, G, C.POINTER(wl_body), f32, i32, C.c_uint32, P]),
+    "wl_pressure_force_body": (i32, [P, G, C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_viscous_force_body": (i32, [P, G, f32, C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_sim_measure_body": (i32, [P, C.POINTER(wl_body), f32, P]),
+    "wl_sim_pressure_force_body": (i32, [P, C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_sim_viscous_force_body": (i32, [P, C.POINTER(wl_body), C.POINTER(f64), P]),
 
     "wl_sim_viscous_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),
 }

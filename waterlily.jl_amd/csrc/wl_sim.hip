@@ -55,41 +55,51 @@ __device__ __forceinline__ float kern1_(float d) { return (1 - d * d) / 4 - (d *
 __device__ __forceinline__ float eps_at(float d) { d = fabsf(d); return d == 0.f ? 1.4e-45f : nextafterf(d, INFINITY) - d; }
 __device__ __forceinline__ float mu0_(float d, float e) { return d / e < -1 + sqrtf(eps_at(d)) ? 0.f : kern0_(fminf(d / e, 1.f)); }
 __device__ __forceinline__ float mu1_(float d, float e) { return e * kern1_(fminf(fmaxf(d / e, -1.f), 1.f)); }
-// measure(body,x): sphere sdf, AutoBody closed form   src/AutoBody.jl:29-37
+// Closed-form AutoBody (src/AutoBody.jl:21,29-37): kind 1 sdf = |m∘(x−c)|−R (sphere/circle; an axis with m=0 is dropped: cylinder
+// along it), kind 2 sdf = m·(x−c) (plane, m need not be unit).  The map x−V·t is folded into c by the caller, V is the body velocity.
+struct BodyArg { int kind; float c[3], R, m[3], V[3]; };
 template <int D>
-__device__ __forceinline__ void sphere_measure(const float* x, const float* c, float R, float fastd2, float& d, float* n) {
+__device__ __forceinline__ float body_sdf(const BodyArg& b, const float* x) {
   float s = 0.f;
-  for (int q = 0; q < D; q++) { n[q] = 0.f; s += (x[q] - c[q]) * (x[q] - c[q]); }
-  const float rr = sqrtf(s);
-  d = rr - R;
-  if (d * d > fastd2) return;
+  if (b.kind == 2) { for (int q = 0; q < D; q++) s += b.m[q] * (x[q] - b.c[q]); return s; }
+  for (int q = 0; q < D; q++) { const float dx = b.m[q] * (x[q] - b.c[q]); s += dx * dx; }
+  return sqrtf(s) - b.R;
+}
+// measure(body,x;fastd²): returns true when n was evaluated (then V = the body velocity), false on the early exits (n = V = 0)
+template <int D>
+__device__ __forceinline__ bool body_measure(const BodyArg& b, const float* x, float fastd2, float& d, float* n) {
+  float rr = 0.f;
+  for (int q = 0; q < D; q++) n[q] = 0.f;
+  if (b.kind == 2) d = body_sdf<D>(b, x);
+  else { float s = 0.f; for (int q = 0; q < D; q++) { const float dx = b.m[q] * (x[q] - b.c[q]); s += dx * dx; } rr = sqrtf(s); d = rr - b.R; }
+  if (d * d > fastd2) return false;
   float gq[3]; bool nan = false;
-  for (int q = 0; q < D; q++) { gq[q] = (x[q] - c[q]) / rr; nan = nan || isnan(gq[q]); }
-  if (nan) return;
+  for (int q = 0; q < D; q++) { gq[q] = b.kind == 2 ? b.m[q] : (b.m[q] * (x[q] - b.c[q])) / rr; nan = nan || isnan(gq[q]); }
+  if (nan) return false;
   float mm = 0.f; for (int q = 0; q < D; q++) mm += gq[q] * gq[q];
   mm = sqrtf(mm); d /= mm;
   for (int q = 0; q < D; q++) n[q] = gq[q] / mm;
+  return true;
 }
 // measure!(flow,body;ϵ) for the sphere: fills σ(sdf), μ₀, μ₁, V(=0) on the interior   src/Body.jl:28-48
 template <int D>
-__global__ void k_measure_sphere(GridX g, float* __restrict__ sig, float* __restrict__ mu0, float* __restrict__ mu1, float c0, float c1, float c2, float R, float e) {
+__global__ void k_measure_body(GridX g, float* __restrict__ sig, float* __restrict__ mu0, float* __restrict__ mu1, float* __restrict__ V, BodyArg bd, float e) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
   const int k = g.k0 + pz;
   const long o = m + (long)k * g.sz;
-  const float c[3] = {c0, c1, c2};
   const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
   float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
-  float s = 0.f; for (int q = 0; q < D; q++) s += (x[q] - c[q]) * (x[q] - c[q]);
-  const float dc = sqrtf(s) - R;
+  const float dc = body_sdf<D>(bd, x);
   sig[o] = dc;
   const float d2 = (2 + e) * (2 + e);
   if (dc * dc < d2) {
     for (int a = 0; a < D; a++) {
       float xf[3]; for (int q = 0; q < 3; q++) xf[q] = x[q] - ((q == a) ? 0.5f : 0.f);
-      float di, ni[3]; sphere_measure<D>(xf, c, R, d2, di, ni);
+      float di, ni[3]; const bool full = body_measure<D>(bd, xf, d2, di, ni);
       di = fabsf(di) <= 0.5f ? di : copysignf(di, dc);
+      if (full && bd.V[a] != 0.f) V[(long)a * g.cs + o] = bd.V[a];       // (V was zero-filled: Body.jl:29)
       mu0[(long)a * g.cs + o] = mu0_(di, e);
       for (int b = 0; b < D; b++) mu1[(long)(a + b * D) * g.cs + o] = mu1_(di, e) * ni[b];
     }
@@ -99,17 +109,16 @@ __global__ void k_measure_sphere(GridX g, float* __restrict__ sig, float* __rest
 }
 // pressure_force: Σ_inside p[I]·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:116-133
 template <int D>
-__global__ void k_pforce_sphere(GridX g, const float* __restrict__ p, float c0, float c1, float c2, float R, double* __restrict__ part) {
+__global__ void k_pforce_body(GridX g, const float* __restrict__ p, BodyArg bd, double* __restrict__ part) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc[3] = {0, 0, 0};
-  const float c[3] = {c0, c1, c2};
   const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
     for (int k = g.k0 + pz; k < g.k1; k += nsl) {
       const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
       float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
-      float d, n[3]; sphere_measure<D>(x, c, R, 1.f, d, n);
+      float d, n[3]; body_measure<D>(bd, x, 1.f, d, n);
       const float kk = kern_(fminf(fmaxf(d, -1.f), 1.f));
       const float pv = p[m + (long)k * g.sz];
       for (int a = 0; a < D; a++) acc[a] += (double)(pv * (n[a] * kk));
@@ -120,18 +129,17 @@ __global__ void k_pforce_sphere(GridX g, const float* __restrict__ p, float c0, 
 }
 // viscous_force: Σ_inside −2ν·S(I,u)·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:140-154, ∂(i,j,I,u) :42-44
 template <int D>
-__global__ void k_vforce_sphere(GridX g, const float* __restrict__ u, float nu, float c0, float c1, float c2, float R, double* __restrict__ part) {
+__global__ void k_vforce_body(GridX g, const float* __restrict__ u, float nu, BodyArg bd, double* __restrict__ part) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc[3] = {0, 0, 0};
-  const float c[3] = {c0, c1, c2};
   const long st[3] = {1, g.sy, g.sz};
   const int nsl = wl_nslots(g);
   if (cell_ij(g, m, i, j) && interior_ij(g, i, j)) {
     for (int k = g.k0 + pz; k < g.k1; k += nsl) {
       const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 1};
       float x[3]; for (int q = 0; q < 3; q++) x[q] = (float)I[q] - 1.5f;
-      float d, n[3]; sphere_measure<D>(x, c, R, 1.f, d, n);
+      float d, n[3]; body_measure<D>(bd, x, 1.f, d, n);
       const float kk = kern_(fminf(fmaxf(d, -1.f), 1.f));
       const long o = m + (long)k * g.sz;
       auto du = [&](int a, int b) -> float {       // ∂u_a/∂x_b at the cell centre
@@ -599,43 +607,78 @@ int wl_sim_apply_ic(wl_sim* s, int kind, void* st) {
   }
   WL_LAUNCH_CHECK(); return 0;
 }
-int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* st) {
-  WL_CHECK(s->d.has_body && s->mu1 && s->V, "simulation was created with has_body=0");
-  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D; const size_t nc = (size_t)G.cs;
-  WL_TRY(wl::fill(s->V, 0.f, nc * D, q)); WL_TRY(wl::fill(s->mu0, 1.f, nc * D, q)); WL_TRY(wl::fill(s->mu1, 0.f, nc * D * D, q));   // Body.jl:29
-  DSEL(D, k_measure_sphere, wl_plane_grid(G, G.k1 - G.k0), dim3(WL_BLOCK), 0, q, G, s->sigma, s->mu0, s->mu1, c[0], c[1], D == 3 ? c[2] : 0.f, R, eps);
+static int to_body_arg(int D, const wl_body* b, BodyArg* o) {
+  WL_CHECK(b && (b->kind == WL_BODY_SPHERE || b->kind == WL_BODY_PLANE), "wl_body.kind must be WL_BODY_SPHERE or WL_BODY_PLANE");
+  o->kind = b->kind; o->R = b->R;
+  float mm = 0.f;
+  for (int q = 0; q < 3; q++) { o->c[q] = q < D ? b->c[q] : 0.f; o->m[q] = q < D ? b->m[q] : 0.f; o->V[q] = q < D ? b->V[q] : 0.f; mm += o->m[q] * o->m[q]; }
+  WL_CHECK(mm > 0.f, "wl_body.m (axis mask / plane normal) is zero");
+  return 0;
+}
+static wl_body sphere_body(const float* c, float R) {
+  wl_body b{}; b.kind = WL_BODY_SPHERE; b.R = R;
+  for (int q = 0; q < 3; q++) { b.c[q] = c[q]; b.m[q] = 1.f; }
+  return b;
+}
+// measure!(flow,body;ϵ) on the caller's arrays (without the halo exchange / update!(pois) of the composite)   src/Body.jl:28-51
+static int measure_fields(float* sigma, float* mu0, float* mu1, float* V, const GridX& G, const BodyArg& bd, float eps, int exitBC, unsigned perdir, hipStream_t q) {
+  const int D = G.D; const size_t nc = (size_t)G.cs;
+  WL_TRY(wl::fill(V, 0.f, nc * D, q)); WL_TRY(wl::fill(mu0, 1.f, nc * D, q)); WL_TRY(wl::fill(mu1, 0.f, nc * D * D, q));             // Body.jl:29
+  DSEL(D, k_measure_body, wl_plane_grid(G, G.k1 - G.k0), dim3(WL_BLOCK), 0, q, G, sigma, mu0, mu1, V, bd, eps);
   WL_LAUNCH_CHECK();
   const float zero[3] = {0, 0, 0};
-  WL_TRY(wl::bc_vec(s->mu0, G, zero, 0, s->d.perdir_mask, q));                                                                     // Body.jl:49
-  WL_TRY(wl::bc_vec(s->V, G, zero, s->d.exitBC, s->d.perdir_mask, q));                                                              // Body.jl:50
+  WL_TRY(wl::bc_vec(mu0, G, zero, 0, perdir, q));                                                                                   // Body.jl:49
+  return wl::bc_vec(V, G, zero, exitBC, perdir, q);                                                                                 // Body.jl:50
+}
+// which: 0 pressure_force(p) (src/Metrics.jl:116-133), 1 viscous_force(u,ν) (:140-154); Float64 partial sums, flow.f untouched
+static int force_reduce(int which, const float* a, float nu, const GridX& G, const BodyArg& bd, const RedWs& ws, double* out, hipStream_t q) {
+  const int D = G.D;
+  dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
+  // partials need 3*grid.x doubles (<= 3*WL_REDPART): pa and pb are contiguous (2*WL_MAXPART doubles)
+  if (which == 0) { DSEL(D, k_pforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, bd, ws.pa); }
+  else { DSEL(D, k_vforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, nu, bd, ws.pa); }
+  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, ws.pa, (int)grid.x, ws.res_d + 4);
+  WL_LAUNCH_CHECK();
+  WlCtx& cx = wl_ctx();
+  WL_HIP(hipMemcpyAsync(cx.h_d, ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
+  WL_HIP(hipStreamSynchronize(q));
+  for (int c = 0; c < D; c++) out[c] = cx.h_d[c];
+  return 0;
+}
+int wl_measure_body(float* sigma, float* mu0, float* mu1, float* V, const wl_grid* g, const wl_body* body, float eps, int exitBC, uint32_t perdir_mask, void* st) {
+  WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_CHECK(sigma && mu0 && mu1 && V, "null field");
+  BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
+  return measure_fields(sigma, mu0, mu1, V, gx(*g), bd, eps, exitBC, perdir_mask, wl_stream(st));
+}
+int wl_pressure_force_body(const float* p, const wl_grid* g, const wl_body* body, double* out, void* st) {
+  WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
+  BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
+  return force_reduce(0, p, 0.f, gx(*g), bd, wl_red_ws(wl_ctx().red), out, wl_stream(st));
+}
+int wl_viscous_force_body(const float* u, const wl_grid* g, float nu, const wl_body* body, double* out, void* st) {
+  WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
+  BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
+  return force_reduce(1, u, nu, gx(*g), bd, wl_red_ws(wl_ctx().red), out, wl_stream(st));
+}
+int wl_sim_measure_body(wl_sim* s, const wl_body* body, float eps, void* st) {
+  WL_CHECK(s->d.has_body && s->mu1 && s->V, "simulation was created with has_body=0");
+  BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
+  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
+  WL_TRY(measure_fields(s->sigma, s->mu0, s->mu1, s->V, G, bd, eps, s->d.exitBC, s->d.perdir_mask, q));
   WL_TRY(wl::halo(s->comm, s->mu0, G, D, 2, q)); WL_TRY(wl::halo(s->comm, s->V, G, D, 2, q));
   WL_TRY(s->refresh_body_mask(q));
   return s->mg->update(q);                                                                                                          // WaterLily.jl:148
 }
-int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {
-  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
-  dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
-  // partials need 3*grid.x doubles (<= 3*WL_REDPART): pa and pb are contiguous (2*WL_MAXPART doubles)
-  DSEL(D, k_pforce_sphere, grid, dim3(WL_BLOCK), 0, q, G, (const float*)s->p, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
-  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)grid.x, s->mg->ws.res_d + 4);
-  WL_LAUNCH_CHECK();
-  WlCtx& cx = wl_ctx();
-  WL_HIP(hipMemcpyAsync(cx.h_d, s->mg->ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
-  WL_HIP(hipStreamSynchronize(q));
-  for (int a = 0; a < D; a++) out[a] = cx.h_d[a];
-  return 0;
+int wl_sim_pressure_force_body(wl_sim* s, const wl_body* body, double* out, void* st) {
+  BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
+  return force_reduce(0, s->p, 0.f, s->G, bd, s->mg->ws, out, wl_stream(st));
 }
-int wl_sim_viscous_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) {
-  hipStream_t q = wl_stream(st); const GridX& G = s->G; const int D = s->d.D;
+int wl_sim_viscous_force_body(wl_sim* s, const wl_body* body, double* out, void* st) {
   WL_CHECK(!s->comm, "viscous_force on slabs is not built");
-  dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
-  DSEL(D, k_vforce_sphere, grid, dim3(WL_BLOCK), 0, q, G, (const float*)s->u, s->d.nu, c[0], c[1], D == 3 ? c[2] : 0.f, R, s->mg->ws.pa);
-  hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, s->mg->ws.pa, (int)grid.x, s->mg->ws.res_d + 4);
-  WL_LAUNCH_CHECK();
-  WlCtx& cx = wl_ctx();
-  WL_HIP(hipMemcpyAsync(cx.h_d, s->mg->ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
-  WL_HIP(hipStreamSynchronize(q));
-  for (int a = 0; a < D; a++) out[a] = cx.h_d[a];
-  return 0;
+  BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
+  return force_reduce(1, s->u, s->d.nu, s->G, bd, s->mg->ws, out, wl_stream(st));
 }
+int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* st) { const wl_body b = sphere_body(c, R); return wl_sim_measure_body(s, &b, eps, st); }
+int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) { const wl_body b = sphere_body(c, R); return wl_sim_pressure_force_body(s, &b, out, st); }
+int wl_sim_viscous_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) { const wl_body b = sphere_body(c, R); return wl_sim_viscous_force_body(s, &b, out, st); }
 }  // extern "C"

@@ -182,5 +182,43 @@ function WaterLily.update!(m::WaterLily.MeanFlow{Float32,<:HA}, flow::WaterLily.
     push!(m.t, m.t[end] + dt)
 end
 
-export HipArray, HipMultiLevel
+# ---- closed-form bodies (SURVEY row f1) --------------------------------------------------------------------------
+# An AutoBody holds arbitrary Julia closures, which cannot be shipped to a HIP kernel through a C ABI.  The shapes whose
+# sdf/gradient are known in closed form get their own AbstractBody type; everything else keeps the reference's host path
+# (measure! on Array fields, then copyto! the HipArrays).
+struct WlBody; kind::Int32; c::NTuple{3,Cfloat}; R::Cfloat; m::NTuple{3,Cfloat}; V::NTuple{3,Cfloat}; end      # include/wlhip.h wl_body
+pad3(v) = ntuple(i -> i <= length(v) ? Cfloat(v[i]) : 0f0, 3)
+"""
+    HipBody(:sphere, c, R; V) | HipBody(:cylinder, c, R, axis; V) | HipBody(:plane, point, normal; V)
+
+sdf = |m∘(x−c)|−R (an axis with m=0 is dropped) or m·(x−c).  `c(t)`/`V(t)` may be functions of time: the translating map
+`x − ∫V dt` of the reference's `AutoBody(sdf, map)` (src/AutoBody.jl:36-37).
+"""
+struct HipBody{C,VV} <: WaterLily.AbstractBody
+    kind::Int32; c::C; R::Float32; m::NTuple{3,Cfloat}; V::VV
+end
+HipBody(s::Symbol, c, a...; V=(0, 0, 0)) =
+    s === :sphere   ? HipBody(Int32(1), c, Float32(a[1]), (1f0, 1f0, 1f0), V) :
+    s === :cylinder ? HipBody(Int32(1), c, Float32(a[1]), ntuple(i -> i == a[2] ? 0f0 : 1f0, 3), V) :
+    s === :plane    ? HipBody(Int32(2), c, 0f0, pad3(a[1]), V) : error("HipBody: :sphere, :cylinder or :plane")
+at(v::Function, t) = v(t); at(v, t) = v
+wlbody(b::HipBody, D, t) = Ref(WlBody(b.kind, pad3(at(b.c, t)), b.R, ntuple(i -> i <= D ? b.m[i] : 0f0, 3), pad3(at(b.V, t))))
+# measure!(a::Flow,body;t,ϵ)  src/Body.jl:28-51
+function WaterLily.measure!(a::HFlow{D}, body::HipBody; t=zero(Float32), ϵ=1) where D
+    chk(ccall((:wl_measure_body, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Cfloat, Cint, Cuint, Ptr{Cvoid}),
+              a.σ.ptr, a.μ₀.ptr, a.μ₁.ptr, a.V.ptr, sgrid(a.σ), wlbody(body, D, t), ϵ, a.exitBC, pmask(a.perdir), C_NULL))
+end
+# pressure_force / viscous_force (src/Metrics.jl:116-133,140-154): Float64 sums on device, flow.f is not used as scratch
+function WaterLily.pressure_force(p::HA, df, body::HipBody, t=0; T=Float64)          # src/Metrics.jl:128
+    out = zeros(Cdouble, 3); D = ndims(p)
+    chk(ccall((:wl_pressure_force_body, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), p.ptr, sgrid(p), wlbody(body, D, t), out, C_NULL))
+    T.(out[1:D])
+end
+function WaterLily.viscous_force(u::HA, ν, df, body::HipBody, t=0; T=Float64)        # src/Metrics.jl:149
+    out = zeros(Cdouble, 3); D = ndims(u) - 1
+    chk(ccall((:wl_viscous_force_body, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), u.ptr, vgrid(u), ν, wlbody(body, D, t), out, C_NULL))
+    T.(out[1:D])
+end
+
+export HipArray, HipMultiLevel, HipBody
 end # module

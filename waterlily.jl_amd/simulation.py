@@ -11,6 +11,38 @@ from .flow import Flow, mom_step_
 from .poisson import MultiLevelPoisson
 
 
+def measure_(a, body, eps=1.0):
+    """measure!(a::Flow, body; ϵ) for a closed-form AutoBody   src/Body.jl:28-51"""
+    from ._lib import make_body
+    from .core import ptr, sgrid, perdir_mask
+    b = make_body(body, a.D)
+    g = sgrid(a.sigma)
+    check(lib().wl_measure_body(ptr(a.sigma), ptr(a.mu0), ptr(a.mu1), ptr(a.V), C.byref(g), C.byref(b), float(eps), int(a.exitBC), perdir_mask(a.perdir), stream()))
+    a.has_body = True
+
+
+def pressure_force(a, body):
+    """pressure_force(p,df,body)   src/Metrics.jl:116-133 (Float64 sums; flow.f is not used as scratch)"""
+    from ._lib import make_body
+    from .core import ptr, sgrid
+    b = make_body(body, a.D)
+    g = sgrid(a.p)
+    out = (C.c_double * 3)()
+    check(lib().wl_pressure_force_body(ptr(a.p), C.byref(g), C.byref(b), out, stream()))
+    return np.array(out[: a.D])
+
+
+def viscous_force(a, body):
+    """viscous_force(u,ν,df,body)   src/Metrics.jl:140-154"""
+    from ._lib import make_body
+    from .core import ptr, sgrid
+    b = make_body(body, a.D)
+    g = sgrid(a.p)
+    out = (C.c_double * 3)()
+    check(lib().wl_viscous_force_body(ptr(a.u), C.byref(g), float(a.nu), C.byref(b), out, stream()))
+    return np.array(out[: a.D])
+
+
 class Simulation:
     """Simulation(dims,uBC,L;U,Δt,ν,ϵ,perdir,exitBC,λ,body,T) over leaf operations (reference orchestration)."""
 
@@ -21,9 +53,9 @@ class Simulation:
             U = float(np.sqrt(sum(float(v) ** 2 for v in uBC)))                  # :100
         self.U, self.L, self.eps = float(U), float(L), eps
         self.flow = Flow(dims, uBC, dt=dt, nu=nu, g=g, u0=u0, perdir=perdir, exitBC=exitBC, lam=lam, T=T, duBC_dt=duBC_dt)   # :103
-        self.body = body
+        self.body = body          # None (NoBody) or a closed-form AutoBody: ("sphere", c, R) | ("cylinder", c, R, axis) | ("plane", point, normal) [+ velocity]
         if body is not None:
-            raise NotImplementedError("bodies go through FusedSimulation.measure_sphere_ this round")
+            measure_(self.flow, body, eps=self.eps)                                                 # :104
         self.pois = MultiLevelPoisson(self.flow.p, self.flow.mu0, self.flow.sigma, perdir=perdir)   # :97,105
 
     def sim_time(self):
@@ -40,9 +72,24 @@ class Simulation:
         while self.sim_time() < t_end and len(self.flow.dt) - steps0 < max_steps:
             self.sim_step_(remeasure=remeasure)
 
-    def measure_(self):
-        """measure!(sim): NoBody => only update!(pois)   :146-149 (quirk Q3: runs every step when remeasure=true)"""
+    def measure_(self, body=None):
+        """measure!(sim): measure!(flow,body) + update!(pois)   :146-149 (quirk Q3: runs every step when remeasure=true; NoBody => only
+        update!).  `body`: the body's new description (position, velocity) — the stand-in for the reference's map(x,t)."""
+        if body is not None:
+            self.body = body
+        if self.body is not None:
+            measure_(self.flow, self.body, eps=self.eps)
         self.pois.update_()
+
+    def pressure_force(self):
+        return pressure_force(self.flow, self.body)
+
+    def viscous_force(self):
+        return viscous_force(self.flow, self.body)
+
+    def total_force(self):
+        """total_force(sim) = pressure_force + viscous_force   src/Metrics.jl:156-161"""
+        return self.pressure_force() + self.viscous_force()
 
 
 class FusedSimulation:
@@ -197,6 +244,30 @@ class FusedSimulation:
         """measure!(sim) for AutoBody(|x-c|-R): closed form on device + update!(pois)"""
         c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
         check(lib().wl_sim_measure_sphere(self._h, c, float(R), float(eps), stream()))
+
+    def measure_body_(self, body, eps=1.0):
+        """measure!(sim) for a closed-form AutoBody — ("sphere", c, R) | ("cylinder", c, R, axis) | ("plane", point, normal), optionally
+        followed by the body's translation velocity (stored in flow.V, src/AutoBody.jl:36-37) — on device + update!(pois)"""
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        check(lib().wl_sim_measure_body(self._h, C.byref(b), float(eps), stream()))
+
+    def pressure_force_body(self, body):
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        out = (C.c_double * 3)()
+        check(lib().wl_sim_pressure_force_body(self._h, C.byref(b), out, stream()))
+        return np.array(out[: self.D])
+
+    def viscous_force_body(self, body):
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        out = (C.c_double * 3)()
+        check(lib().wl_sim_viscous_force_body(self._h, C.byref(b), out, stream()))
+        return np.array(out[: self.D])
+
+    def total_force_body(self, body):
+        return self.pressure_force_body(body) + self.viscous_force_body(body)
 
     def pressure_force_sphere(self, center, R):
         c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))

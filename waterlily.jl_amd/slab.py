@@ -167,6 +167,11 @@ class SlabSimulation:
         c = (C.c_float * 3)(*[float(v) for v in center])
         check(lib().wl_sim_measure_sphere(self._h, c, float(R), float(eps), None))
 
+    def measure_body_(self, body, eps=1.0):
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        check(lib().wl_sim_measure_body(self._h, C.byref(b), float(eps), None))
+
     def sync(self):
         check(lib().wl_stream_sync(None))
 
