@@ -119,6 +119,14 @@ def main():
                 print(f"step {s}: max|du|={du:.3e} n_slab={sim.pois_n[-2:]} n_ref={ref.pois_n[-2:]}", flush=True)
                 assert sim.pois_n == ref.pois_n
                 assert du < 5e-5, du
+        # force read-outs are collective on slabs: every rank sums its planes, the sums are added on device
+        body = ("sphere", c, R)
+        fp, fv = sim.pressure_force_body(body), sim.viscous_force_body(body)
+        if rank == 0:
+            rp, rv = ref.pressure_force_body(body), ref.viscous_force_body(body)
+            print(f"forces: slab p={fp} v={fv}  single p={rp} v={rv}", flush=True)
+            assert np.abs(rp).max() > 0 and np.allclose(fp, rp, rtol=1e-3, atol=1e-3 * np.abs(rp).max())
+            assert np.abs(rv).max() > 0 and np.allclose(fv, rv, rtol=1e-3, atol=1e-3 * np.abs(rv).max())
         dist.barrier()
         del sim
         comm.destroy()

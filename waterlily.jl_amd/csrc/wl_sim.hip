@@ -630,8 +630,9 @@ static int measure_fields(float* sigma, float* mu0, float* mu1, float* V, const 
   WL_TRY(wl::bc_vec(mu0, G, zero, 0, perdir, q));                                                                                   // Body.jl:49
   return wl::bc_vec(V, G, zero, exitBC, perdir, q);                                                                                 // Body.jl:50
 }
-// which: 0 pressure_force(p) (src/Metrics.jl:116-133), 1 viscous_force(u,ν) (:140-154); Float64 partial sums, flow.f untouched
-static int force_reduce(int which, const float* a, float nu, const GridX& G, const BodyArg& bd, const RedWs& ws, double* out, hipStream_t q) {
+// which: 0 pressure_force(p) (src/Metrics.jl:116-133), 1 viscous_force(u,ν) (:140-154); Float64 partial sums, flow.f untouched.
+// On z-slabs every rank sums its own planes and the per-rank sums are added on device (one 128-byte all-gather).
+static int force_reduce(int which, const float* a, float nu, const GridX& G, const BodyArg& bd, const RedWs& ws, wl_comm* comm, double* out, hipStream_t q) {
   const int D = G.D;
   dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
   // partials need 3*grid.x doubles (<= 3*WL_REDPART): pa and pb are contiguous (2*WL_MAXPART doubles)
@@ -639,6 +640,7 @@ static int force_reduce(int which, const float* a, float nu, const GridX& G, con
   else { DSEL(D, k_vforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, nu, bd, ws.pa); }
   hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, ws.pa, (int)grid.x, ws.res_d + 4);
   WL_LAUNCH_CHECK();
+  WL_TRY(wl::combine_results(comm, ws, q));
   WlCtx& cx = wl_ctx();
   WL_HIP(hipMemcpyAsync(cx.h_d, ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
   WL_HIP(hipStreamSynchronize(q));
@@ -653,12 +655,12 @@ int wl_measure_body(float* sigma, float* mu0, float* mu1, float* V, const wl_gri
 int wl_pressure_force_body(const float* p, const wl_grid* g, const wl_body* body, double* out, void* st) {
   WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
   BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
-  return force_reduce(0, p, 0.f, gx(*g), bd, wl_red_ws(wl_ctx().red), out, wl_stream(st));
+  return force_reduce(0, p, 0.f, gx(*g), bd, wl_red_ws(wl_ctx().red), nullptr, out, wl_stream(st));
 }
 int wl_viscous_force_body(const float* u, const wl_grid* g, float nu, const wl_body* body, double* out, void* st) {
   WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
   BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
-  return force_reduce(1, u, nu, gx(*g), bd, wl_red_ws(wl_ctx().red), out, wl_stream(st));
+  return force_reduce(1, u, nu, gx(*g), bd, wl_red_ws(wl_ctx().red), nullptr, out, wl_stream(st));
 }
 int wl_sim_measure_body(wl_sim* s, const wl_body* body, float eps, void* st) {
   WL_CHECK(s->d.has_body && s->mu1 && s->V, "simulation was created with has_body=0");
@@ -671,12 +673,12 @@ int wl_sim_measure_body(wl_sim* s, const wl_body* body, float eps, void* st) {
 }
 int wl_sim_pressure_force_body(wl_sim* s, const wl_body* body, double* out, void* st) {
   BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
-  return force_reduce(0, s->p, 0.f, s->G, bd, s->mg->ws, out, wl_stream(st));
+  return force_reduce(0, s->p, 0.f, s->G, bd, s->mg->ws, s->comm, out, wl_stream(st));
 }
 int wl_sim_viscous_force_body(wl_sim* s, const wl_body* body, double* out, void* st) {
-  WL_CHECK(!s->comm, "viscous_force on slabs is not built");
   BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
-  return force_reduce(1, s->u, s->d.nu, s->G, bd, s->mg->ws, out, wl_stream(st));
+  WL_TRY(s->sync_u(wl_stream(st)));                  // ∂u/∂z at the slab faces reads the neighbours' planes
+  return force_reduce(1, s->u, s->d.nu, s->G, bd, s->mg->ws, s->comm, out, wl_stream(st));
 }
 int wl_sim_measure_sphere(wl_sim* s, const float* c, float R, float eps, void* st) { const wl_body b = sphere_body(c, R); return wl_sim_measure_body(s, &b, eps, st); }
 int wl_sim_pressure_force_sphere(wl_sim* s, const float* c, float R, double* out, void* st) { const wl_body b = sphere_body(c, R); return wl_sim_pressure_force_body(s, &b, out, st); }

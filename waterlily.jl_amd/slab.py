@@ -172,6 +172,25 @@ class SlabSimulation:
         b = make_body(body, self.D)
         check(lib().wl_sim_measure_body(self._h, C.byref(b), float(eps), None))
 
+    def pressure_force_body(self, body):
+        """pressure_force(sim) over all slabs — collective: every rank calls it and gets the global value"""
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        out = (C.c_double * 3)()
+        check(lib().wl_sim_pressure_force_body(self._h, C.byref(b), out, None))
+        return np.array(out[:3])
+
+    def viscous_force_body(self, body):
+        """viscous_force(sim) over all slabs — collective"""
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        out = (C.c_double * 3)()
+        check(lib().wl_sim_viscous_force_body(self._h, C.byref(b), out, None))
+        return np.array(out[:3])
+
+    def total_force_body(self, body):
+        return self.pressure_force_body(body) + self.viscous_force_body(body)
+
     def sync(self):
         check(lib().wl_stream_sync(None))
 
