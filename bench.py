@@ -173,9 +173,9 @@ def main():
         return slab.bench_main(args, world, rank, local_rank, read_prof=read_prof, build_roofline=build_roofline)
 
     sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
-    for opt in ("convz", "fused_smoother", "fuse_p", "constl", "pair", "convm", "fuse_cfl", "store_f", "tail", "jacobi_march"):      # A/B switches for experiments: WL_OPT_convz=0 etc. (defaults: fast paths on)
-        if os.environ.get("WL_OPT_" + opt) is not None:
-            sim.set_option(opt, int(os.environ["WL_OPT_" + opt]))
+    for key, val in os.environ.items():      # A/B switches for experiments: WL_OPT_<option of wl_sim_set_option>=0/1 (defaults: fast paths on)
+        if key.startswith("WL_OPT_"):
+            sim.set_option(key[7:], int(val))
     for _ in range(args.warmup):
         sim.mom_step_()
     sim.sync()

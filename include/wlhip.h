@@ -173,7 +173,10 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    "constl"[1] constant-coefficient (NoBody) kernels        "fuse_p"[1] fused projection head (div+scale+residual!) and tail
    "fuse_cfl"[1] CFL folded into the corrector's tail       "tail"[1] smallest V-cycle levels in one launch
    "store_f"[0] materialise the intermediates f, z          "store_eps"[0] materialise the smoother's final ϵ
-   "overlap"[1] u exchange on a second stream (slabs)       "convz"[0], "convm"[0] alternative conv_diff! kernels (slower) */
+   "overlap"[1] u exchange on a second stream (slabs)       "convz"[0], "convm"[0] alternative conv_diff! kernels (slower)
+   "jacobi_march"[1] z-marching constant-coefficient Jacobi  "farmask"[1], "hybrid"[1] BDIM! fast paths away from a body
+   "zsplit"[1] pair smoother on the planes away from a body (levels >= 32 M cells; 2: any size)
+   "defer_shift"[1] residual!'s mean shift + solver!'s first norms folded into the finest level's z-marching Jacobi! */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
    g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).

@@ -743,3 +743,28 @@ def test_reference_orchestration_with_a_body(w, oracle, body):
     vo = so.viscous_force()
     assert np.allclose(sl.viscous_force(), vo, rtol=2e-3, atol=2e-3 * max(np.abs(vo).max(), 1e-6))
     assert np.allclose(sl.total_force(), so.total_force(), rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+
+
+@pytest.mark.parametrize("case", ["tgv", "sphere", "tgv_odd"])
+def test_residual_shift_and_norms_without_a_pass_over_r(w, case):
+    """residual!'s mean shift (src/Poisson.jl:95-97) and solver!'s first L₁/L∞ (src/MultiLevelPoisson.jl:111) without a pass of their own:
+    the finest level's z-marching Jacobi! (the V-cycle's first operation) shifts r as it loads it and accumulates the norms.  Same
+    iteration counts, Δt and fields as with the plain pass (a level with a body keeps the pass)."""
+    N = 64
+    res = {}
+    for mode in ("plain", "defer"):
+        if case == "tgv":
+            sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+        elif case == "tgv_odd":
+            sim = w.FusedSimulation((N + 6, N - 4, N + 2), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+        else:
+            sim = w.FusedSimulation((N, N, N), (1, 0, 0), 16.0, U=1, nu=16.0 / 250, has_body=True)
+        sim.set_option("defer_shift", int(mode == "defer"))
+        if case == "sphere":
+            sim.measure_sphere_((N / 4, N / 2 - 1, N / 2 - 1), 8.0, 1.0)
+        for _ in range(6):
+            sim.mom_step_()
+        res[mode] = (sim.field("u"), sim.field("p"), sim.pois_n, sim.dt)
+    for mode in ("defer",):
+        assert res[mode][2] == res["plain"][2] and res[mode][3] == res["plain"][3], mode
+        assert np.array_equal(res[mode][0], res["plain"][0]) and np.array_equal(res[mode][1], res["plain"][1]), mode

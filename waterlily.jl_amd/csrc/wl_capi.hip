@@ -257,7 +257,8 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
     ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
     if (!perdir && (!fine.dist || fine.cl.on)) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
       WL_TRY(halo(fine, fine.r, 1, s));              // (slab: ϵ=r·iD of the neighbour's boundary plane is recomputed from its r; iD is evaluated from the position)
-      WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s));
+      if (l == 0 && shift_pending) { shift_pending = false; WL_TRY(wl::jacobi_pp_shift(fine.eps, fine.r, fine.x, fine.x_, 1.f, fine.cl, ws, 1, 0, s)); }
+      else WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s));
       std::swap(fine.r, fine.eps);
     } else {
       WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
@@ -298,7 +299,10 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
       WL_TRY(wl::residual_part(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));             // r and the local Σr -> res_d[0]
     }
     WL_TRY(wl::combine_results(comm, ws, s));
-    WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));                                  // mean shift + r₁ -> res_d[1], r∞ -> res_f[0]
+    // mean shift + r₁ -> res_d[1], r∞ -> res_f[0] — unless the V-cycle's first operation is the z-marching Jacobi! on this level
+    // (always run: nᵖ ≥ 1): that kernel applies the shift as it loads r and accumulates the norms, no pass over r at all
+    shift_pending = defer_shift && itmx >= 1 && !(comm && comm->size > 1) && !perdir && lv.size() > 1 && wl::jacobi_takes_shift(p.x_, p.cl);
+    if (!shift_pending) WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));
   }
   double hd[3]; float hf[2];
   float w = 1.f;

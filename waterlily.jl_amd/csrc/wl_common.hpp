@@ -243,6 +243,8 @@ int gs_init(float* eps, const float* r, const float* iD, const GridX& g, hipStre
 int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const GridX& g, int k0, hipStream_t s);
 int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s);
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s);
+bool jacobi_takes_shift(const GridX& g, const ConstL& cl);
+int jacobi_pp_shift(float* rout, const float* r, float* x, const GridX& g, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 // coarse tail of the V-cycle in one launch (wl_poisson.hip)
 #define WL_TAIL_MAXLV 8

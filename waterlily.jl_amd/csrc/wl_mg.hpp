@@ -26,6 +26,8 @@ struct wl_mg {
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
   bool use_zsplit = true;   // body levels: constant-coefficient pair kernels on the planes away from the body, general kernels on the rest
   long zsplit_min = 32L << 20;   // ... on levels of at least this many cells (smaller ranges do not fill 256 CUs: 256³ loses 4 %, 384³ gains 4 %, 512³ 7 %)
+  bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
+  bool shift_pending = false;
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
   bool tail_ok(int first) const;
   int tail(int first, float w, hipStream_t s);

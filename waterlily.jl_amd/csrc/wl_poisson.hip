@@ -434,15 +434,23 @@ __global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* _
 // only — the in-plane coefficients and, for each of the three z-classes of a plane (0/1/2 open z-faces), D and iD of the cell
 // and iD of its four in-plane neighbours — is looked up once; r[k±1] come from a register window.  ≈4× fewer instructions per
 // cell than the plane kernel, which was instruction-bound (≈200 VALU instructions for 16 B/cell).
-__global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl, int zchunk) {
+// SHIFT: residual!'s mean shift (src/Poisson.jl:95-97) is still pending on r — it is applied to the seven values as they are loaded
+// (ghost cells: (0−s)·iD = ∓0 since their iD is 0) and L₁/L∞ of the shifted residual (solver!'s first norms) are accumulated on the way.
+template <int SHIFT>
+__global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl, int zchunk,
+                                  const double* __restrict__ sum, double n_inside, double* __restrict__ part, float* __restrict__ pmax) {
   __shared__ float sDt[27], siDt[27];
   if (threadIdx.x < 27) { sDt[threadIdx.x] = cl.Dt[threadIdx.x]; siDt[threadIdx.x] = cl.iDt[threadIdx.x]; }
   __syncthreads();
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
-  if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
+  float c = 0.f;
+  if (SHIFT) { const float sm = (float)(*sum) / (float)n_inside; c = (fabsf(sm) <= 2.f * 1.1920929e-7f) ? 0.f : sm; }
+  float acc = 0.f, mx = 0.f;      // a thread's |r| over its ≤ zchunk planes in Float32, across threads in Float64
   const int ks = g.k0 + pz * zchunk, ke = (ks + zchunk < g.k1) ? ks + zchunk : g.k1;
-  if (ks >= ke) return;
+  const bool live = cell_ij(g, m, i, j) && interior_ij(g, i, j) && ks < ke;
+  if (!SHIFT && !live) return;
+  if (live) {
   const int I0 = i + 1, I1 = j + 1;
   const int cx0 = wl::wl_cl_cnt(I0, g.nx), cxm = wl::wl_cl_cnt(I0 - 1, g.nx), cxp = wl::wl_cl_cnt(I0 + 1, g.nx);
   const int cy0 = wl::wl_cl_cnt(I1, g.ny), cym = wl::wl_cl_cnt(I1 - 1, g.ny), cyp = wl::wl_cl_cnt(I1 + 1, g.ny);
@@ -457,20 +465,26 @@ __global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float
   }
   auto pick = [](const float* t, int c) -> float { return c == 2 ? t[2] : (c == 1 ? t[1] : t[0]); };
   long o = m + (long)ks * g.sz;
-  float rm = r[o - g.sz], r0 = r[o];
+  float rm = r[o - g.sz] - c, r0 = r[o] - c;
   for (int k = ks; k < ke; k++, o += g.sz) {
-    const float rp = r[o + g.sz];
+    const float rp = r[o + g.sz] - c;
+    if (SHIFT) { const float av = fabsf(r0); acc += av; mx = fmaxf(mx, av); }
     const int I2 = g.gk + k + 1;
     const int cz0 = wl::wl_cl_cnt(I2, g.gnz), czm = wl::wl_cl_cnt(I2 - 1, g.gnz), czp = wl::wl_cl_cnt(I2 + 1, g.gnz);   // uniform
     const float lz = wl::wl_cl_coef(I2, g.gnz, cl.c[2]), lzp = wl::wl_cl_coef(I2 + 1, g.gnz, cl.c[2]);
     const float e0 = r0 * pick(id0, cz0);
     float s = e0 * pick(d0, cz0);
-    s += ((r[o - 1] * pick(idxm, cz0)) * lx + (r[o + 1] * pick(idxp, cz0)) * lxp);
-    s += ((r[o - g.sy] * pick(idym, cz0)) * ly + (r[o + g.sy] * pick(idyp, cz0)) * lyp);
+    s += (((r[o - 1] - c) * pick(idxm, cz0)) * lx + ((r[o + 1] - c) * pick(idxp, cz0)) * lxp);
+    s += (((r[o - g.sy] - c) * pick(idym, cz0)) * ly + ((r[o + g.sy] - c) * pick(idyp, cz0)) * lyp);
     s += ((rm * pick(id0, czm)) * lz + (rp * pick(id0, czp)) * lzp);
     rout[o] = r0 - w * s;
     x[o] = x[o] + w * e0;
     rm = r0; r0 = rp;
+  }
+  }
+  if (SHIFT) {
+    const double accd = block_sum((double)acc); mx = block_max(mx);
+    if (threadIdx.x == 0) { part[blockIdx.x] = accd; pmax[blockIdx.x] = mx; }
   }
 }
 template <int D>
@@ -814,10 +828,21 @@ int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, 
 }
 static int g_jacobi_march = 1;
 void jacobi_march_enable(int on) { g_jacobi_march = on; }
+bool jacobi_takes_shift(const GridX& g, const ConstL& cl) { return cl.on && g.D == 3 && g_jacobi_march && g.nz == g.gnz; }
+// Jacobi! on a residual whose mean shift is still pending (Σr in ws.res_d[0]): shift on load, L₁ -> res_d[slot_d], L∞ -> res_f[slot_f]
+int jacobi_pp_shift(float* rout, const float* r, float* x, const GridX& g, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
+  if (!jacobi_takes_shift(g, cl)) { wl_set_error("jacobi_pp_shift: level not eligible"); return WL_EINVAL; }
+  const int zc = wl_march_chunk(g, g.k1 - g.k0);
+  dim3 grid = wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc));
+  const double ni = (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz});
+  hipLaunchKernelGGL(k_jacobi_march_cl<1>, grid, dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc, (const double*)(ws.res_d + 0), ni, ws.pa, ws.pm);
+  hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)grid.x, ws.res_d + slot_d, ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
 int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s) {
   if (cl.on && g.D == 3 && g_jacobi_march) {
     const int zc = wl_march_chunk(g, g.k1 - g.k0);
-    hipLaunchKernelGGL(k_jacobi_march_cl, wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc)), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc);
+    hipLaunchKernelGGL(k_jacobi_march_cl<0>, wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc)), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc, (const double*)nullptr, 0.0, (double*)nullptr, (float*)nullptr);
   } else if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
   else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
   WL_LAUNCH_CHECK(); return 0;
@@ -842,7 +867,8 @@ int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* 
 }
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
   dim3 grid = wl_plane_grid(g, wl_red_slots(g, g.k1 - g.k0));
-  hipLaunchKernelGGL(k_shift_norms, grid, dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz}), ws.pa, ws.pm);
+  const double ni = (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz});
+  hipLaunchKernelGGL(k_shift_norms, grid, dim3(WL_BLOCK), 0, s, g, r, ws.res_d + 0, ni, ws.pa, ws.pm);
   hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)grid.x, ws.res_d + slot_d, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
