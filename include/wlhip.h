@@ -205,6 +205,12 @@ typedef struct wl_body { int32_t kind; float c[3]; float R; float m[3]; float V[
 int wl_measure_body(float* sigma, float* mu0, float* mu1, float* V, const wl_grid* g, const wl_body* host_body, float eps, int exitBC, uint32_t perdir_mask, void* stream);
 int wl_pressure_force_body(const float* p, const wl_grid* g, const wl_body* host_body, double out[3], void* stream);
 int wl_viscous_force_body(const float* u, const wl_grid* g, float nu, const wl_body* host_body, double out[3], void* stream);
+/* pressure_moment(x₀,p,df,body) / viscous_moment(x₀,u,ν,df,body) (src/Metrics.jl:169-188): moments about host_x0[D]; in 2-D the scalar
+ * moment is returned in out[0] and out[1] (the reference's broadcast) */
+int wl_pressure_moment_body(const float* host_x0, const float* p, const wl_grid* g, const wl_body* host_body, double out[3], void* stream);
+int wl_viscous_moment_body(const float* host_x0, const float* u, const wl_grid* g, float nu, const wl_body* host_body, double out[3], void* stream);
+int wl_sim_pressure_moment_body(wl_sim* s, const float* host_x0, const wl_body* host_body, double out[3], void* stream);
+int wl_sim_viscous_moment_body(wl_sim* s, const float* host_x0, const wl_body* host_body, double out[3], void* stream);
 int wl_sim_measure_body(wl_sim* s, const wl_body* host_body, float eps, void* stream);          /* measure! + update!(pois) */
 int wl_sim_pressure_force_body(wl_sim* s, const wl_body* host_body, double out[3], void* stream); /* src/Metrics.jl:116-133 */
 int wl_sim_viscous_force_body(wl_sim* s, const wl_body* host_body, double out[3], void* stream);  /* src/Metrics.jl:140-154 */

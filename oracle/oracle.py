@@ -95,6 +95,10 @@ def lib(omp=False):
         ("wlo_body_measure", None, [C.c_int, C.c_int, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p, C.c_void_p, dbl, C.c_void_p]),
         ("wlo_pressure_force_body", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
         ("wlo_viscous_force_body", None, [C.c_int, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
+        ("wlo_pressure_moment_body", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
+        ("wlo_viscous_moment_body", None, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, dbl, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, dbl, C.c_void_p, C.c_void_p]),
+        ("wlo_sim_pressure_moment", None, [C.c_void_p, C.c_void_p, C.c_void_p]),
+        ("wlo_sim_viscous_moment", None, [C.c_void_p, C.c_void_p, C.c_void_p]),
         ("wlo_sim_time", dbl, [C.c_void_p]),
         ("wlo_sim_flow_time", dbl, [C.c_void_p]),
         ("wlo_sim_dt", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
@@ -351,6 +355,23 @@ def viscous_force_body(u, nu, df, body):
     return np.array(list(out))
 
 
+def pressure_moment_body(x0, p, df, body):
+    """pressure_moment(x₀,p,df,body)   src/Metrics.jl:169-174"""
+    kind, c, R, m, _ = _body(body, p.ndim)
+    out = (C.c_double * p.ndim)()
+    lib().wlo_pressure_moment_body(_dt(p), p.ndim, _dbls(x0), _ptr(p), _ptr(df), _ints(p.shape), kind, c, R, m, out)
+    return np.array(list(out))
+
+
+def viscous_moment_body(x0, u, nu, df, body):
+    """viscous_moment(x₀,u,ν,df,body)   src/Metrics.jl:183-188"""
+    D = u.ndim - 1
+    kind, c, R, m, _ = _body(body, D)
+    out = (C.c_double * D)()
+    lib().wlo_viscous_moment_body(_dt(u), D, _dbls(x0), _ptr(u), float(nu), _ptr(df), _ints(u.shape[:D]), kind, c, R, m, out)
+    return np.array(list(out))
+
+
 def _view(ptr, shape, dtype):
     n = int(np.prod(shape))
     buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
@@ -571,6 +592,20 @@ class Simulation:
     def total_force(self):
         """total_force(sim) = pressure_force + viscous_force   src/Metrics.jl:156-161"""
         return self.pressure_force() + self.viscous_force()
+
+    def pressure_moment(self, x0):
+        out = (C.c_double * self.D)()
+        self._lib.wlo_sim_pressure_moment(self.h, _dbls(x0), out)
+        return np.array(list(out))
+
+    def viscous_moment(self, x0):
+        out = (C.c_double * self.D)()
+        self._lib.wlo_sim_viscous_moment(self.h, _dbls(x0), out)
+        return np.array(list(out))
+
+    def total_moment(self, x0):
+        """total_moment(x₀,sim)   src/Metrics.jl:195"""
+        return self.pressure_moment(x0) + self.viscous_moment(x0)
 
     def pois_norm(self, which):
         return self._lib.wlo_sim_pois_norm(self.h, {"L1": 0, "Linf": 1, "L2": 2}[which])

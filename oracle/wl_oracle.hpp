@@ -821,6 +821,47 @@ void viscous_force(const V<T, D>& u, T nu, const V<T, D>& df, const Body<T, D>& 
   for (int i = 1; i <= D; i++) { double s = 0; S<T, D> c = df.comp(i); for (long k = 0; k < c.len(); k++) s += (double)c.p[k]; out[i - 1] = s; }
 }
 
+// cross(a,b): 3-D vector product; in 2-D the scalar a₁b₂−a₂b₁, which the broadcast df[I,:] .= … stores in every component
+template <class T, int D> inline void cross_(const T* a, const T* b, T* out) {
+  if (D == 2) { const T m = a[0] * b[1] - a[1] * b[0]; out[0] = m; out[1] = m; }
+  else { out[0] = a[1] * b[2] - a[2] * b[1]; out[1] = a[2] * b[0] - a[0] * b[2]; out[2] = a[0] * b[1] - a[1] * b[0]; }
+}
+// pressure_moment(x₀,p,df,body,t): df[I,:] = p[I]·cross(loc(0,I)−x₀, nds)                     src/Metrics.jl:169-174
+template <class T, int D>
+void pressure_moment(const T* x0, const S<T, D>& p, const V<T, D>& df, const Body<T, D>& body, double* out) {
+  std::fill(df.p, df.p + df.len(), (T)0);
+  for_box<D>(inside<D>(p.n), [&](const CI<D>& I) {
+    T x[D]; loc<T, D>(0, I, x);
+    T d, nrm[D], Vv[D]; body.measure(x, (T)1, d, nrm, Vv);
+    const T k = kern<T>(std::min(std::max(d, (T)-1), (T)1));
+    T nds[D], r[D], c[D];
+    for (int j = 0; j < D; j++) { nds[j] = nrm[j] * k; r[j] = x[j] - x0[j]; }
+    cross_<T, D>(r, nds, c);
+    for (int i = 1; i <= D; i++) df(I, i) = p(I) * c[i - 1];
+  });
+  for (int i = 1; i <= D; i++) { double s = 0; S<T, D> c = df.comp(i); for (long k = 0; k < c.len(); k++) s += (double)c.p[k]; out[i - 1] = s; }
+}
+// viscous_moment(x₀,u,ν,df,body,t): df[I,:] = −2ν·cross(loc(0,I)−x₀, S(I,u)·nds)              src/Metrics.jl:183-188
+template <class T, int D>
+void viscous_moment(const T* x0, const V<T, D>& u, T nu, const V<T, D>& df, const Body<T, D>& body, double* out) {
+  std::fill(df.p, df.p + df.len(), (T)0);
+  for_box<D>(inside<D>(df.n), [&](const CI<D>& I) {
+    T x[D]; loc<T, D>(0, I, x);
+    T d, nrm[D], Vv[D]; body.measure(x, (T)1, d, nrm, Vv);
+    const T k = kern<T>(std::min(std::max(d, (T)-1), (T)1));
+    T nds[D], r[D], sn[D], c[D];
+    for (int j = 0; j < D; j++) { nds[j] = nrm[j] * k; r[j] = x[j] - x0[j]; }
+    for (int i = 1; i <= D; i++) {
+      T acc = 0;
+      for (int j = 1; j <= D; j++) { const T Sij = (dudx<T, D>(i, j, I, u) + dudx<T, D>(j, i, I, u)) / 2; acc += Sij * nds[j - 1]; }
+      sn[i - 1] = acc;
+    }
+    cross_<T, D>(r, sn, c);
+    for (int i = 1; i <= D; i++) df(I, i) = (-2 * nu) * c[i - 1];
+  });
+  for (int i = 1; i <= D; i++) { double s = 0; S<T, D> c = df.comp(i); for (long k = 0; k < c.len(); k++) s += (double)c.p[k]; out[i - 1] = s; }
+}
+
 // ----------------------------------------------------------------------------------------------
 // Simulation                                                                src/WaterLily.jl:86-149
 // ----------------------------------------------------------------------------------------------

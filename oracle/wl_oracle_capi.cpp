@@ -165,6 +165,14 @@ void wlo_body_measure(int dtype, int D, int kind, const double* c, double R, con
 void wlo_pressure_force_body(int dtype, int D, void* p, void* df, const int* dims, int kind, const double* c, double R, const double* m, double* out) {
   DISPATCH(dtype, D, { Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, nullptr); pressure_force<T, DD>(mkS<T, DD>(p, dims), mkV<T, DD>(df, dims), b, out); });
 }
+void wlo_pressure_moment_body(int dtype, int D, const double* x0, void* p, void* df, const int* dims, int kind, const double* c, double R, const double* m, double* out) {
+  DISPATCH(dtype, D, { Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, nullptr); T xx[DD]; for (int k = 0; k < DD; k++) xx[k] = (T)x0[k];
+                       pressure_moment<T, DD>(xx, mkS<T, DD>(p, dims), mkV<T, DD>(df, dims), b, out); });
+}
+void wlo_viscous_moment_body(int dtype, int D, const double* x0, void* u, double nu, void* df, const int* dims, int kind, const double* c, double R, const double* m, double* out) {
+  DISPATCH(dtype, D, { Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, nullptr); T xx[DD]; for (int k = 0; k < DD; k++) xx[k] = (T)x0[k];
+                       viscous_moment<T, DD>(xx, mkV<T, DD>(u, dims), (T)nu, mkV<T, DD>(df, dims), b, out); });
+}
 void wlo_viscous_force_body(int dtype, int D, void* u, double nu, void* df, const int* dims, int kind, const double* c, double R, const double* m, double* out) {
   DISPATCH(dtype, D, { Body<T, DD> b = mkBody<T, DD>(kind, c, R, m, nullptr); viscous_force<T, DD>(mkV<T, DD>(u, dims), (T)nu, mkV<T, DD>(df, dims), b, out); });
 }
@@ -303,6 +311,12 @@ void* wlo_sim_level_field(void* h, int l, const char* name) {
   return out;
 }
 void wlo_sim_pressure_force(void* h, double* out) { SIM(h, (pressure_force<T, DD>(sim->flow.p, sim->flow.f, sim->body, out))); }
+void wlo_sim_pressure_moment(void* h, const double* x0, double* out) {
+  SIM(h, { T xx[DD]; for (int k = 0; k < DD; k++) xx[k] = (T)x0[k]; pressure_moment<T, DD>(xx, sim->flow.p, sim->flow.f, sim->body, out); });
+}
+void wlo_sim_viscous_moment(void* h, const double* x0, double* out) {
+  SIM(h, { T xx[DD]; for (int k = 0; k < DD; k++) xx[k] = (T)x0[k]; viscous_moment<T, DD>(xx, sim->flow.u, sim->flow.nu, sim->flow.f, sim->body, out); });
+}
 void wlo_sim_viscous_force(void* h, double* out) { SIM(h, (viscous_force<T, DD>(sim->flow.u, sim->flow.nu, sim->flow.f, sim->body, out))); }
 double wlo_sim_pois_norm(void* h, int which) { double o = 0; SIM(h, { auto* P = sim->pois.levels[0]; o = which == 0 ? (double)P->L1() : (which == 1 ? (double)P->Linf() : (double)P->L2()); }); return o; }
 // sub-phases of mom_step! for per-phase parity checks: 0 u⁰.=u;scale_u!(0)  1 mom_predict!  2 mom_project!(w=1)  3 mom_correct!  4 mom_project!(w=.5)  5 push!(Δt,CFL)

@@ -697,6 +697,11 @@ def test_closed_form_bodies_measure_steps_and_forces(w, oracle, body):
     assert np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())
     vo, vg = so.viscous_force(), sg.viscous_force_body(body)
     assert np.allclose(vg, vo, rtol=2e-3, atol=2e-3 * max(np.abs(vo).max(), 1e-6))
+    x0 = (14.0, 12.5, 17.0)                                                     # pressure_moment / viscous_moment about a point (src/Metrics.jl:169-188)
+    mo, mg = so.pressure_moment(x0), sg.pressure_moment_body(x0, body)
+    assert np.abs(mo).max() > 0 and np.allclose(mg, mo, rtol=2e-3, atol=2e-3 * np.abs(mo).max())
+    wo, wg = so.viscous_moment(x0), sg.viscous_moment_body(x0, body)
+    assert np.allclose(wg, wo, rtol=2e-3, atol=2e-3 * max(np.abs(wo).max(), 1e-6))
 
 
 def test_moving_cylinder_remeasure_every_step(w, oracle):
@@ -743,6 +748,9 @@ def test_reference_orchestration_with_a_body(w, oracle, body):
     vo = so.viscous_force()
     assert np.allclose(sl.viscous_force(), vo, rtol=2e-3, atol=2e-3 * max(np.abs(vo).max(), 1e-6))
     assert np.allclose(sl.total_force(), so.total_force(), rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+    x0 = (10.0, 16.0, 13.5)
+    mo = so.total_moment(x0)
+    assert np.abs(mo).max() > 0 and np.allclose(sl.total_moment(x0), mo, rtol=2e-3, atol=2e-3 * np.abs(mo).max())
 
 
 @pytest.mark.parametrize("case", ["tgv", "sphere", "tgv_odd"])
@@ -768,3 +776,25 @@ def test_residual_shift_and_norms_without_a_pass_over_r(w, case):
     for mode in ("defer",):
         assert res[mode][2] == res["plain"][2] and res[mode][3] == res["plain"][3], mode
         assert np.array_equal(res[mode][0], res["plain"][0]) and np.array_equal(res[mode][1], res["plain"][1]), mode
+
+
+def test_moments_2d_hydrostatic(w, oracle):
+    """the reference's moment tests on the device (test/test_metrics.jl:58-66): a fluid at rest has no viscous moment, p = y no
+    pressure moment about the circle's centre; about a point shifted by a in x the moment is a·F_y (both slots hold the 2-D scalar)."""
+    N = 34                                                                      # array extent (32 interior cells: a·2ⁿ for the multigrid)
+    R = 8
+    body = ("sphere", (N / 2, N / 2), R)
+    sim = w.Simulation((N - 2, N - 2), (0.0, 0.0), N, U=1, nu=1.0, body=body)
+    p = np.zeros((N, N), dtype=np.float32, order="F")
+    for b in range(1, N - 1):
+        p[1:-1, b] = b - 0.5
+    sim.flow.p.copy_(w.to_device(p))
+    assert np.all(sim.viscous_moment((N / 2, N / 2)) == 0)
+    Fy = sim.pressure_force()[1]
+    assert abs(Fy / (np.pi * R**2) - 1) < 2e-3                                  # test_metrics.jl:40
+    m0 = sim.pressure_moment((N / 2, N / 2))
+    assert abs(m0[0]) < 1e-4 * abs(Fy)
+    ms = sim.pressure_moment((N / 2 - 3.0, N / 2))
+    assert np.isclose(ms[0], 3.0 * Fy, rtol=1e-4) and ms[0] == ms[1]
+    df = np.zeros((N, N, 2), dtype=np.float32, order="F")
+    assert np.allclose(ms, oracle.pressure_moment_body((N / 2 - 3.0, N / 2), p, df, body), rtol=1e-5)

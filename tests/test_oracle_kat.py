@@ -378,3 +378,28 @@ def test_cylinder_and_plane_bodies(oracle):
     assert col[0] == 0 and col[-1] == 1 and np.all(np.diff(col) >= 0)
     assert np.isclose(mu0[5, 5, 1], 0.5)          # 0-based index 5 = I 6: its lower y-face sits at y = 6 − 1.5 − ½ = 4 → d = 0 → μ₀ = ½
     assert np.all(sim.field("V") == 0)
+
+
+# ------------------------------------------------------------------ test/test_metrics.jl:58-66
+def test_moments_known_answers(oracle):
+    """viscous moment of a fluid at rest is zero; a hydrostatic pressure p = y exerts no moment about the body's centre (2-D: the
+    scalar moment, 3-D: all three components); and, beyond the reference's tests, p = y about a point shifted by a in x gives the
+    moment −a·F_y of the buoyancy force F = (0, πR², 0) applied at the centre (r×F with r = centre − x₀)."""
+    N = 32
+    body2, body3 = ("sphere", (N / 2, N / 2), N // 4), ("sphere", (N / 2, N / 2, N / 2), N // 4)
+    u2, u3 = F((N, N, 2), np.float64), F((N, N, N, 3), np.float64)
+    df2, df3 = F((N, N, 2), np.float64), F((N, N, N, 3), np.float64)
+    assert np.all(oracle.viscous_moment_body((N / 2, N / 2), u2, 1.0, df2, body2) == 0)                     # :60
+    assert np.all(oracle.viscous_moment_body((N / 2,) * 3, u3, 1.0, df3, body3) == 0)                       # :61
+    p2, p3 = F((N, N), np.float64), F((N, N, N), np.float64)
+    for b in range(1, N - 1):
+        p2[1:-1, b] = oracle.loc(0, (2, b + 1))[1]
+        p3[1:-1, b, 1:-1] = oracle.loc(0, (2, b + 1, 2))[1]
+    m2 = oracle.pressure_moment_body((N / 2, N / 2), p2, df2, body2)
+    assert abs(m2[0]) < 1e-9 * N**3                                                                         # :65
+    m3 = oracle.pressure_moment_body((N / 2,) * 3, p3, df3, body3)
+    assert np.all(np.abs(m3) < 1e-9 * N**4)                                                                 # :66
+    a = 3.0
+    Fy = oracle.pressure_force_body(p2, df2, body2)[1]
+    m2s = oracle.pressure_moment_body((N / 2 - a, N / 2), p2, df2, body2)
+    assert np.isclose(m2s[0], a * Fy, rtol=1e-9) and m2s[0] == m2s[1]          # r = (a,0), F = (0,Fy): r×F = a·Fy; 2-D: scalar in both slots

@@ -9,4 +9,5 @@ from .flow import BDIM_, CFL, Flow, conv_diff_, mom_correct_, mom_predict_, mom_
 from .poisson import (pcg_, poisson_solver_, GaussSeidelRB_, Jacobi_, L1, Linf, MultiLevelPoisson, Poisson, increment_, mult_, norms, prolongate_,  # noqa: F401
                       residual_, restrict_, restrictL_, set_diag_, smooth_, update_)
 from .metrics import MeanFlow, load_checkpoint, save_checkpoint  # noqa: F401
-from .simulation import FusedSimulation, Simulation, measure_, pressure_force, viscous_force  # noqa: F401
+from .simulation import (FusedSimulation, Simulation, measure_, pressure_force, pressure_moment, viscous_force,  # noqa: F401
+                         viscous_moment)

@@ -143,6 +143,10 @@ SIGNATURES = {
     "wl_measure_body": (i32, [P, P, P, P, G, C.POINTER(wl_body), f32, i32, C.c_uint32, P]),
     "wl_pressure_force_body": (i32, [P, G, C.POINTER(wl_body), C.POINTER(f64), P]),
     "wl_viscous_force_body": (i32, [P, G, f32, C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_pressure_moment_body": (i32, [C.POINTER(f32), P, G, C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_viscous_moment_body": (i32, [C.POINTER(f32), P, G, f32, C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_sim_pressure_moment_body": (i32, [P, C.POINTER(f32), C.POINTER(wl_body), C.POINTER(f64), P]),
+    "wl_sim_viscous_moment_body": (i32, [P, C.POINTER(f32), C.POINTER(wl_body), C.POINTER(f64), P]),
     "wl_sim_measure_body": (i32, [P, C.POINTER(wl_body), f32, P]),
     "wl_sim_pressure_force_body": (i32, [P, C.POINTER(wl_body), C.POINTER(f64), P]),
     "wl_sim_viscous_force_body": (i32, [P, C.POINTER(wl_body), C.POINTER(f64), P]),

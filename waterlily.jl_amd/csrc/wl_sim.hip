@@ -107,9 +107,16 @@ __global__ void k_measure_body(GridX g, float* __restrict__ sig, float* __restri
     for (int a = 0; a < D; a++) mu0[(long)a * g.cs + o] = 0.f;
   }
 }
+// cross(a,b) as the reference's broadcast stores it: the 3-D vector product, in 2-D the scalar a₁b₂−a₂b₁ in every component
+template <int D>
+__device__ __forceinline__ void cross_(const float* a, const float* b, float* o) {
+  if (D == 2) { const float m = a[0] * b[1] - a[1] * b[0]; o[0] = m; o[1] = m; o[2] = 0.f; }
+  else { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+}
+struct MomArg { int on; float x0[3]; };      // on: moments about x0 (pressure_moment / viscous_moment, src/Metrics.jl:169-188) instead of forces
 // pressure_force: Σ_inside p[I]·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:116-133
 template <int D>
-__global__ void k_pforce_body(GridX g, const float* __restrict__ p, BodyArg bd, double* __restrict__ part) {
+__global__ void k_pforce_body(GridX g, const float* __restrict__ p, BodyArg bd, MomArg mo, double* __restrict__ part) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc[3] = {0, 0, 0};
@@ -121,7 +128,14 @@ __global__ void k_pforce_body(GridX g, const float* __restrict__ p, BodyArg bd, 
       float d, n[3]; body_measure<D>(bd, x, 1.f, d, n);
       const float kk = kern_(fminf(fmaxf(d, -1.f), 1.f));
       const float pv = p[m + (long)k * g.sz];
-      for (int a = 0; a < D; a++) acc[a] += (double)(pv * (n[a] * kk));
+      if (mo.on) {
+        float nds[3] = {0.f, 0.f, 0.f}, rr[3] = {0.f, 0.f, 0.f}, cr[3];
+        for (int a = 0; a < D; a++) { nds[a] = n[a] * kk; rr[a] = x[a] - mo.x0[a]; }
+        cross_<D>(rr, nds, cr);
+        for (int a = 0; a < D; a++) acc[a] += (double)(pv * cr[a]);
+      } else {
+        for (int a = 0; a < D; a++) acc[a] += (double)(pv * (n[a] * kk));
+      }
     }
   }
   const long b = blockIdx.x, nb = gridDim.x;
@@ -129,7 +143,7 @@ __global__ void k_pforce_body(GridX g, const float* __restrict__ p, BodyArg bd, 
 }
 // viscous_force: Σ_inside −2ν·S(I,u)·n·kern(clamp(d,-1,1)) in Float64   src/Metrics.jl:140-154, ∂(i,j,I,u) :42-44
 template <int D>
-__global__ void k_vforce_body(GridX g, const float* __restrict__ u, float nu, BodyArg bd, double* __restrict__ part) {
+__global__ void k_vforce_body(GridX g, const float* __restrict__ u, float nu, BodyArg bd, MomArg mo, double* __restrict__ part) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc[3] = {0, 0, 0};
@@ -147,10 +161,21 @@ __global__ void k_vforce_body(GridX g, const float* __restrict__ u, float nu, Bo
         if (a == b) return f[o + st[a]] - f[o];
         return (f[o + st[b]] + f[o + st[b] + st[a]] - f[o - st[b]] - f[o - st[b] + st[a]]) / 4;
       };
-      for (int a = 0; a < D; a++) {
-        float v = 0.f;
-        for (int b = 0; b < D; b++) { const float Sab = (du(a, b) + du(b, a)) / 2; v += ((-2 * nu) * Sab) * (n[b] * kk); }
-        acc[a] += (double)v;
+      if (mo.on) {
+        float sn[3] = {0.f, 0.f, 0.f}, rr[3] = {0.f, 0.f, 0.f}, cr[3];
+        for (int a = 0; a < D; a++) {
+          float v = 0.f;
+          for (int b = 0; b < D; b++) { const float Sab = (du(a, b) + du(b, a)) / 2; v += Sab * (n[b] * kk); }
+          sn[a] = v; rr[a] = x[a] - mo.x0[a];
+        }
+        cross_<D>(rr, sn, cr);
+        for (int a = 0; a < D; a++) acc[a] += (double)((-2 * nu) * cr[a]);
+      } else {
+        for (int a = 0; a < D; a++) {
+          float v = 0.f;
+          for (int b = 0; b < D; b++) { const float Sab = (du(a, b) + du(b, a)) / 2; v += ((-2 * nu) * Sab) * (n[b] * kk); }
+          acc[a] += (double)v;
+        }
       }
     }
   }
@@ -633,12 +658,13 @@ static int measure_fields(float* sigma, float* mu0, float* mu1, float* V, const 
 }
 // which: 0 pressure_force(p) (src/Metrics.jl:116-133), 1 viscous_force(u,ν) (:140-154); Float64 partial sums, flow.f untouched.
 // On z-slabs every rank sums its own planes and the per-rank sums are added on device (one 128-byte all-gather).
-static int force_reduce(int which, const float* a, float nu, const GridX& G, const BodyArg& bd, const RedWs& ws, wl_comm* comm, double* out, hipStream_t q) {
+static int force_reduce(int which, const float* a, float nu, const GridX& G, const BodyArg& bd, const RedWs& ws, wl_comm* comm, double* out, hipStream_t q, const float* x0 = nullptr) {
   const int D = G.D;
+  MomArg mo{}; if (x0) { mo.on = 1; for (int c = 0; c < D; c++) mo.x0[c] = x0[c]; }
   dim3 grid = wl_plane_grid(G, wl_red_slots(G, G.k1 - G.k0));
   // partials need 3*grid.x doubles (<= 3*WL_REDPART): pa and pb are contiguous (2*WL_MAXPART doubles)
-  if (which == 0) { DSEL(D, k_pforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, bd, ws.pa); }
-  else { DSEL(D, k_vforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, nu, bd, ws.pa); }
+  if (which == 0) { DSEL(D, k_pforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, bd, mo, ws.pa); }
+  else { DSEL(D, k_vforce_body, grid, dim3(WL_BLOCK), 0, q, G, a, nu, bd, mo, ws.pa); }
   hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, ws.pa, (int)grid.x, ws.res_d + 4);
   WL_LAUNCH_CHECK();
   WL_TRY(wl::combine_results(comm, ws, q));
@@ -662,6 +688,27 @@ int wl_viscous_force_body(const float* u, const wl_grid* g, float nu, const wl_b
   WL_CHECK(wl_grid_ok(g), "bad wl_grid"); WL_TRY(wl_ctx_ensure());
   BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
   return force_reduce(1, u, nu, gx(*g), bd, wl_red_ws(wl_ctx().red), nullptr, out, wl_stream(st));
+}
+int wl_pressure_moment_body(const float* x0, const float* p, const wl_grid* g, const wl_body* body, double* out, void* st) {
+  WL_CHECK(wl_grid_ok(g) && x0, "bad wl_grid / x0"); WL_TRY(wl_ctx_ensure());
+  BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
+  return force_reduce(0, p, 0.f, gx(*g), bd, wl_red_ws(wl_ctx().red), nullptr, out, wl_stream(st), x0);
+}
+int wl_viscous_moment_body(const float* x0, const float* u, const wl_grid* g, float nu, const wl_body* body, double* out, void* st) {
+  WL_CHECK(wl_grid_ok(g) && x0, "bad wl_grid / x0"); WL_TRY(wl_ctx_ensure());
+  BodyArg bd; WL_TRY(to_body_arg(g->D, body, &bd));
+  return force_reduce(1, u, nu, gx(*g), bd, wl_red_ws(wl_ctx().red), nullptr, out, wl_stream(st), x0);
+}
+int wl_sim_pressure_moment_body(wl_sim* s, const float* x0, const wl_body* body, double* out, void* st) {
+  WL_CHECK(x0, "null x0");
+  BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
+  return force_reduce(0, s->p, 0.f, s->G, bd, s->mg->ws, s->comm, out, wl_stream(st), x0);
+}
+int wl_sim_viscous_moment_body(wl_sim* s, const float* x0, const wl_body* body, double* out, void* st) {
+  WL_CHECK(x0, "null x0");
+  BodyArg bd; WL_TRY(to_body_arg(s->d.D, body, &bd));
+  WL_TRY(s->sync_u(wl_stream(st)));
+  return force_reduce(1, s->u, s->d.nu, s->G, bd, s->mg->ws, s->comm, out, wl_stream(st), x0);
 }
 int wl_sim_measure_body(wl_sim* s, const wl_body* body, float eps, void* st) {
   WL_CHECK(s->d.has_body && s->mu1 && s->V, "simulation was created with has_body=0");

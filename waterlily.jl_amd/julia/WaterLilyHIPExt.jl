@@ -220,5 +220,16 @@ function WaterLily.viscous_force(u::HA, ν, df, body::HipBody, t=0; T=Float64)  
     T.(out[1:D])
 end
 
+function WaterLily.pressure_moment(x₀, p::HA, df, body::HipBody, t=0)                                       # src/Metrics.jl:169
+    out = zeros(Cdouble, 3); D = ndims(p)
+    chk(ccall((:wl_pressure_moment_body, libwlhip), Cint, (Ref{NTuple{3,Cfloat}}, Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), Ref(pad3(x₀)), p.ptr, sgrid(p), wlbody(body, D, t), out, C_NULL))
+    out[1:D]
+end
+function WaterLily.viscous_moment(x₀, u::HA, ν, df, body::HipBody, t=0)                                     # src/Metrics.jl:183
+    out = zeros(Cdouble, 3); D = ndims(u) - 1
+    chk(ccall((:wl_viscous_moment_body, libwlhip), Cint, (Ref{NTuple{3,Cfloat}}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), Ref(pad3(x₀)), u.ptr, vgrid(u), ν, wlbody(body, D, t), out, C_NULL))
+    out[1:D]
+end
+
 export HipArray, HipMultiLevel, HipBody
 end # module

@@ -43,6 +43,30 @@ def viscous_force(a, body):
     return np.array(out[: a.D])
 
 
+def pressure_moment(x0, a, body):
+    """pressure_moment(x₀,flow,body)   src/Metrics.jl:168-174"""
+    from ._lib import make_body
+    from .core import ptr, sgrid
+    b = make_body(body, a.D)
+    g = sgrid(a.p)
+    out = (C.c_double * 3)()
+    xx = (C.c_float * 3)(*([float(v) for v in x0] + [0.0] * (3 - a.D)))
+    check(lib().wl_pressure_moment_body(xx, ptr(a.p), C.byref(g), C.byref(b), out, stream()))
+    return np.array(out[: a.D])
+
+
+def viscous_moment(x0, a, body):
+    """viscous_moment(x₀,flow,body)   src/Metrics.jl:182-188"""
+    from ._lib import make_body
+    from .core import ptr, sgrid
+    b = make_body(body, a.D)
+    g = sgrid(a.p)
+    out = (C.c_double * 3)()
+    xx = (C.c_float * 3)(*([float(v) for v in x0] + [0.0] * (3 - a.D)))
+    check(lib().wl_viscous_moment_body(xx, ptr(a.u), C.byref(g), float(a.nu), C.byref(b), out, stream()))
+    return np.array(out[: a.D])
+
+
 class Simulation:
     """Simulation(dims,uBC,L;U,Δt,ν,ϵ,perdir,exitBC,λ,body,T) over leaf operations (reference orchestration)."""
 
@@ -90,6 +114,16 @@ class Simulation:
     def total_force(self):
         """total_force(sim) = pressure_force + viscous_force   src/Metrics.jl:156-161"""
         return self.pressure_force() + self.viscous_force()
+
+    def pressure_moment(self, x0):
+        return pressure_moment(x0, self.flow, self.body)
+
+    def viscous_moment(self, x0):
+        return viscous_moment(x0, self.flow, self.body)
+
+    def total_moment(self, x0):
+        """total_moment(x₀,sim)   src/Metrics.jl:195"""
+        return self.pressure_moment(x0) + self.viscous_moment(x0)
 
 
 class FusedSimulation:
@@ -268,6 +302,25 @@ class FusedSimulation:
 
     def total_force_body(self, body):
         return self.pressure_force_body(body) + self.viscous_force_body(body)
+
+    def _moment(self, fn, x0, body):
+        from ._lib import make_body
+        b = make_body(body, self.D)
+        out = (C.c_double * 3)()
+        xx = (C.c_float * 3)(*([float(v) for v in x0] + [0.0] * (3 - self.D)))
+        check(fn(self._h, xx, C.byref(b), out, stream()))
+        return np.array(out[: self.D])
+
+    def pressure_moment_body(self, x0, body):
+        """pressure_moment(x₀,sim)   src/Metrics.jl:167-174"""
+        return self._moment(lib().wl_sim_pressure_moment_body, x0, body)
+
+    def viscous_moment_body(self, x0, body):
+        """viscous_moment(x₀,sim)   src/Metrics.jl:181-188"""
+        return self._moment(lib().wl_sim_viscous_moment_body, x0, body)
+
+    def total_moment_body(self, x0, body):
+        return self.pressure_moment_body(x0, body) + self.viscous_moment_body(x0, body)
 
     def pressure_force_sphere(self, center, R):
         c = (C.c_float * 3)(*([float(v) for v in center] + [0.0] * (3 - self.D)))
