@@ -81,6 +81,16 @@ __global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, fl
   const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
   const IDX st[3] = {1, (IDX)g.sy, (IDX)g.sz};
   float out[3];
+#ifdef WL_CD_INNER
+  // Experiment (off): waves whose 64 cells are all ≥ 2 cells away from every boundary take the variant without clamped addresses,
+  // boundary flux forms and masked accumulation — a wave-uniform branch, ≈520 instead of 806 VALU instructions for ≈73 % of the
+  // waves at 512³.  Measured: no change in kernel time (the 69 loads per cell are the same) — see DESIGN.md §4.
+  bool inner = true;
+#pragma unroll
+  for (int c = 0; c < D; c++) inner = inner && I[c] >= 3 && I[c] <= N[c] - 2;
+  if (PER == 0 && __all(inner)) cd_cell<D, SCH, PER, IDX, 1, 0>(g, u, o, I, N, st, nu, per, nullptr, out);
+  else
+#endif
   cd_cell<D, SCH, PER, IDX, 0, 0>(g, u, o, I, N, st, nu, per, nullptr, out);
   if (FUSE == 2) {
     // Flow with a body.  Far from it (μ₁ ≡ 0, V ≡ 0 in this workgroup's cells of this plane) BDIM! degenerates to the NoBody form and is
