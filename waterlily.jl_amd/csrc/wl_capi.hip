@@ -1,5 +1,6 @@
 // C ABI of libwlhip.so (see include/wlhip.h): context, leaf wrappers and the MultiLevelPoisson handle.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -68,7 +69,9 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
       // stay distributed while the local planes pair up and the level is still big; otherwise replicate on every rank
       // levels of <= 64 planes are replicated: their halo exchanges would be pure latency (7 per V-cycle and level) while the
       // whole level costs less than that to recompute on every rank
-      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > 64;
+      // (WL_REPLICATE_PLANES overrides the 64: the tests use it to build, with 4 ranks, the small distributed slabs an 8-rank run has)
+      static const int repl = [] { const char* e = getenv("WL_REPLICATE_PLANES"); const int v = e ? atoi(e) : 64; return v >= 8 ? v : 64; }();
+      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > repl;
       if (cz && (nloc % 2 != 0)) { wl_set_error("z-slab: local plane count must stay even until the level is replicated (use nz = P*2^k)"); return WL_EINVAL; }
       if (keep) {
         cgr.gnz = gnz_c; cgr.k0 = f.k0; cgr.k1 = cgr.k0 + nc; cgr.nz = nc + 2 * cgr.k0;
