@@ -209,7 +209,14 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
       // ϵ_mid (3 planes) + r' (2 planes) before B — instead of one exchange per colour sweep
       WL_TRY(halo(p, p.r, 1, s, 2));
       { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s)); }
-      WL_TRY(halo(p, p.em, 1, s, 3)); WL_TRY(halo(p, p.rs, 1, s, 2));
+      {   // one RCCL group for both arrays: one exchange latency instead of two
+        const bool grp = comm && comm->size > 1 && p.dist;
+        if (grp) WL_TRY(comm->group_begin());
+        int rc = halo(p, p.em, 1, s, 3);
+        if (rc == 0) rc = halo(p, p.rs, 1, s, 2);
+        if (grp) { const int rc2 = comm->group_end(); if (rc == 0) rc = rc2; }
+        WL_TRY(rc);
+      }
       { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
     } else {
       WL_TRY(halo(p, p.r, 1, s, 2));
