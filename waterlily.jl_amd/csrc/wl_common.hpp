@@ -1,5 +1,6 @@
 // Shared device/host helpers for libwlhip (gfx950 only; wave = 64).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -71,7 +72,8 @@ static inline int wl_red_slots(const GridX& g, int nplanes) { long by = WL_REDPA
 // up to 32 planes, shorter on small grids so that a launch still has a few thousand workgroups.
 static inline int wl_march_chunk(const GridX& g, int nplanes) {
   const long bp = 8L * wl_strip_blocks(g);
-  long c = (long)nplanes * bp / 4096; if (c > 32) c = 32; if (c < 1) c = 1;
+  static const long cap = [] { const char* e = getenv("WL_MARCH_CHUNK_CAP"); const long v = e ? atol(e) : 32; return v >= 1 ? v : 32; }();   // experiments only
+  long c = (long)nplanes * bp / 4096; if (c > cap) c = cap; if (c < 1) c = 1;
   while ((nplanes + c - 1) / c * bp > 65536 && c < nplanes) c++;      // per-workgroup partials must fit the reduction workspace
   return (int)c;
 }
