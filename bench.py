@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=512, help="interior cells per side of the TGV box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="HIP-event pairs around every phase of the step (phases_ms_per_step); the default run "
+                    "only brackets the roofline kernels — each pair costs a few µs of stream time, ≈1 %% of a 512³ step with all of them on")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -180,7 +182,8 @@ def main():
         sim.mom_step_()
     sim.sync()
     n_warm = len(sim.pois_n)
-    check(lib.wl_prof_enable(1))
+    all_phases = args.phases or any(k.startswith("WL_OPT_") for k in os.environ)
+    check(lib.wl_prof_enable(1 if all_phases else 2))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -200,7 +203,7 @@ def main():
                    "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1]),
                    "constant_coefficient_levels": sim.const_levels(), "smoother_kinds": sim.smoother_kinds()},
         "roofline": roof,
-        "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items()},
+        "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items() if v["launches"]},
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(budget_s=args.cpu_budget)

@@ -252,7 +252,8 @@ int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm);
  *        9 / 10 fine-level kernels A / B of the temporally blocked smoother (wl_fused.hip)                        */
 enum { WL_PROF_GS_SWEEP = 0, WL_PROF_SMOOTH = 1, WL_PROF_JACOBI = 2, WL_PROF_CONVDIFF = 3, WL_PROF_RESIDUAL = 4,
        WL_PROF_BDIM = 5, WL_PROF_PROLONG = 6, WL_PROF_COARSE = 7, WL_PROF_STEP = 8, WL_PROF_GS_A = 9, WL_PROF_GS_B = 10, WL_PROF_NSLOTS = 11 };
-int wl_prof_enable(int on);                                     /* also resets all slots */
+int wl_prof_enable(int on);                                     /* 0 off, 1 all slots, 2 only slots 9 and 10 (each event pair costs a few µs of
+                                                                    stream time); also resets all slots */
 int wl_prof_read(int slot, int* host_count, double* host_total_ms);   /* synchronises the device */
 
 #ifdef __cplusplus

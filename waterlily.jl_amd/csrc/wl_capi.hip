@@ -31,6 +31,7 @@ WlProf& wl_prof() { static WlProf p; return p; }
 ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active(false), idx(0) {
   WlProf& p = wl_prof();
   if (!p.on || id < 0) return;
+  if (p.only_roofline && id != WL_PROF_GS_A && id != WL_PROF_GS_B) return;
   WlProf::Slot& sl = p.slot[id];
   if (sl.used >= 16384) return;
   if (sl.used >= sl.a.size()) { hipEvent_t ea, eb; if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return; sl.a.push_back(ea); sl.b.push_back(eb); }
@@ -352,7 +353,7 @@ int wl_prof_enable(int on) {
   WlProf& p = wl_prof();
   WL_HIP(hipDeviceSynchronize());
   for (int q = 0; q < WL_PROF_NSLOTS; q++) p.slot[q].used = 0;
-  p.on = on != 0;
+  p.on = on != 0; p.only_roofline = on == 2;
   return 0;
 }
 int wl_prof_read(int slot, int* count, double* total_ms) {

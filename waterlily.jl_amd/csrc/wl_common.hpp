@@ -160,6 +160,7 @@ int wl_ctx_ensure();
 // ---- measurement hooks: event pairs on the launch stream (see wlhip.h WL_PROF_*) ----------------------
 struct WlProf {
   bool on = false;
+  bool only_roofline = false;   // wl_prof_enable(2): event pairs only around the finest level's smoother kernels A and B
   struct Slot { std::vector<hipEvent_t> a, b; size_t used = 0; };
   Slot slot[WL_PROF_NSLOTS];
 };

@@ -274,7 +274,7 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
     sim.sync()
     n_warm = len(sim.pois_n)
     if rank == 0 and read_prof is not None:
-        check(lib().wl_prof_enable(1))          # HIP-event pairs around rank 0's finest-level smoother kernels
+        check(lib().wl_prof_enable(2))          # HIP-event pairs around rank 0's finest-level smoother kernels only
     dist.barrier()
     torch.cuda.synchronize()
     cs0 = comm_stats(comm)
