@@ -269,7 +269,7 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
     if (!perdir && (!fine.dist || fine.cl.on)) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
       WL_TRY(halo(fine, fine.r, 1, s));              // (slab: ϵ=r·iD of the neighbour's boundary plane is recomputed from its r; iD is evaluated from the position)
       if (l == 0 && shift_pending) { shift_pending = false; WL_TRY(wl::jacobi_pp_shift(fine.eps, fine.r, fine.x, fine.x_, 1.f, fine.cl, ws, 1, 0, s)); }
-      else WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s));
+      else { const int xz = fine.xzero ? 1 : 0; fine.xzero = false; WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s, xz)); }
       std::swap(fine.r, fine.eps);
     } else {
       WL_TRY(wl::gs_init(fine.eps, fine.r, fine.iD, fine.x_, s));
@@ -284,8 +284,12 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
       WL_TRY(wl::restrict_(coarse.r, coarse.view, fine.r, fine.x_, s));
       WL_TRY(wl::allgather_planes(comm, coarse.r, coarse.view, 1, s));
     } else WL_TRY(wl::restrict_(coarse.r, coarse.x_, fine.r, fine.x_, s));
-    WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
-    if (tail_ok(l + 1)) WL_TRY(tail(l + 1, w, s));                                         // everything below in one launch
+    // fill!(coarse.x,0) :92 — folded into the coarse level's Jacobi! when that is what touches x next (single-domain level, one-pass
+    // Jacobi kernels): its ghost cells are zero since allocation and nothing writes them
+    const bool to_tail = tail_ok(l + 1);
+    coarse.xzero = skip_fill && !to_tail && l + 2 < (int)lv.size() && !perdir && !coarse.dist && !coarse.has_view;
+    if (!coarse.xzero) WL_TRY(wl::fill(coarse.x, 0.f, (size_t)coarse.x_.cs, s));
+    if (to_tail) WL_TRY(tail(l + 1, w, s));                                         // everything below in one launch
     else {
       if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s, true));                       // its last step may be deferred into the smooth! below
       WL_TRY(smooth(l + 1, 4, w, s));

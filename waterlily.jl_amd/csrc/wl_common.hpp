@@ -245,7 +245,7 @@ int jacobi(float* eps, float* r, float* x, const float* L, const float* D, const
 int gs_init(float* eps, const float* r, const float* iD, const GridX& g, hipStream_t s);
 int gs_sweep(float* eps, const float* r, const float* L, const float* iD, const GridX& g, int k0, hipStream_t s);
 int gs_init_sweep1(float* eps, const float* r, const float* L, const float* iD, const GridX& g, hipStream_t s);
-int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s);
+int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* D, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s, int xzero = 0);
 bool jacobi_takes_shift(const GridX& g, const ConstL& cl);
 int jacobi_pp_shift(float* rout, const float* r, float* x, const GridX& g, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);

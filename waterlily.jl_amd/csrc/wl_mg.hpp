@@ -10,6 +10,7 @@ struct wl_mg {
     float *L = nullptr, *D = nullptr, *iD = nullptr, *x = nullptr, *eps = nullptr, *r = nullptr, *z = nullptr;
     float *em = nullptr, *rs = nullptr;   // scratch of the fused smoother: ϵ after sweep 2, new residual (ghosts stay zero)
     wl::ConstL cl{};                 // constant-coefficient level (verified at update!)
+    bool xzero = false;              // x ≡ 0 is implied (the V-cycle's fill!(x,0) was skipped): the next Jacobi! writes x instead of updating it
     // body levels: the coefficients deviate from the constant pattern only on planes [za,zb]; smooth! runs the pair kernels on the other planes
     bool part = false; int za = 0, zb = -1; wl::ConstL clp{};
     bool pend = false;       // the V-cycle's prolongate!+increment! of this level is deferred into the next smooth! (fused kernel A)
@@ -26,6 +27,7 @@ struct wl_mg {
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
   bool use_zsplit = true;   // body levels: constant-coefficient pair kernels on the planes away from the body, general kernels on the rest
   long zsplit_min = 32L << 20;   // ... on levels of at least this many cells (smaller ranges do not fill 256 CUs: 256³ loses 4 %, 384³ gains 4 %, 512³ 7 %)
+  bool skip_fill = true;    // Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi! (x = ω·ϵ instead of x += ω·ϵ)
   bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
   bool shift_pending = false;
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)

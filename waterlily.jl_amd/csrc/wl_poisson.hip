@@ -403,7 +403,7 @@ __global__ void k_gs_init_sweep1(GridX g, float* __restrict__ eps, const float* 
 // the old r); the caller then swaps its r/ϵ buffers.  36 instead of 12+36 B/cell.                 src/Poisson.jl:111-114
 // constant-coefficient Jacobi!: L, D, iD evaluated from the cell position (wl::ConstL) — 16 instead of 32 B/cell
 template <int D>
-__global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl) {
+__global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl, int xzero) {
   __shared__ float sDt[27], siDt[27];
   if (threadIdx.x < 27) { sDt[threadIdx.x] = cl.Dt[threadIdx.x]; siDt[threadIdx.x] = cl.iDt[threadIdx.x]; }
   __syncthreads();
@@ -428,7 +428,7 @@ __global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* _
   s += ((r[o - g.sy] * ID(cx0, cym, cz0)) * ly + (r[o + g.sy] * ID(cx0, cyp, cz0)) * lyp);
   if (D == 3) s += ((r[o - g.sz] * ID(cx0, cy0, czm)) * lz + (r[o + g.sz] * ID(cx0, cy0, czp)) * lzp);
   rout[o] = r[o] - w * s;
-  x[o] = x[o] + w * e0;
+  x[o] = (xzero ? 0.f : x[o]) + w * e0;
 }
 // The same Jacobi! as a z-march (3-D): a thread walks a chunk of planes of one interior column.  Everything that depends on (i,j)
 // only — the in-plane coefficients and, for each of the three z-classes of a plane (0/1/2 open z-faces), D and iD of the cell
@@ -438,7 +438,7 @@ __global__ void k_jacobi_pp_cl(GridX g, float* __restrict__ rout, const float* _
 // (ghost cells: (0−s)·iD = ∓0 since their iD is 0) and L₁/L∞ of the shifted residual (solver!'s first norms) are accumulated on the way.
 template <int SHIFT>
 __global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, float w, wl::ConstL cl, int zchunk,
-                                  const double* __restrict__ sum, double n_inside, double* __restrict__ part, float* __restrict__ pmax) {
+                                  const double* __restrict__ sum, double n_inside, double* __restrict__ part, float* __restrict__ pmax, int xzero) {
   __shared__ float sDt[27], siDt[27];
   if (threadIdx.x < 27) { sDt[threadIdx.x] = cl.Dt[threadIdx.x]; siDt[threadIdx.x] = cl.iDt[threadIdx.x]; }
   __syncthreads();
@@ -478,7 +478,7 @@ __global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float
     s += (((r[o - g.sy] - c) * pick(idym, cz0)) * ly + ((r[o + g.sy] - c) * pick(idyp, cz0)) * lyp);
     s += ((rm * pick(id0, czm)) * lz + (rp * pick(id0, czp)) * lzp);
     rout[o] = r0 - w * s;
-    x[o] = x[o] + w * e0;
+    x[o] = (xzero ? 0.f : x[o]) + w * e0;          // xzero: x ≡ 0 on entry (fill!(coarse.x,0) of the V-cycle folded in)
     rm = r0; r0 = rp;
   }
   }
@@ -489,7 +489,7 @@ __global__ void k_jacobi_march_cl(GridX g, float* __restrict__ rout, const float
 }
 template <int D>
 __global__ void k_jacobi_pp(GridX g, float* __restrict__ rout, const float* __restrict__ r, float* __restrict__ x, const float* __restrict__ L,
-                            const float* __restrict__ Dg, const float* __restrict__ iD, float w) {
+                            const float* __restrict__ Dg, const float* __restrict__ iD, float w, int xzero) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j) || !interior_ij(g, i, j)) return;
@@ -509,7 +509,7 @@ __global__ void k_jacobi_pp(GridX g, float* __restrict__ rout, const float* __re
   s += (E(o - g.sy) * ly + E(o + g.sy) * lyp);
   if (D == 3) s += (E(o - g.sz) * lz + E(o + g.sz) * lzp);
   rout[o] = r[o] - w * s;
-  x[o] = x[o] + w * e0;
+  x[o] = (xzero ? 0.f : x[o]) + w * e0;
 }
 // residual!'s mean shift and L₁/L∞ of the shifted residual in ONE pass   src/Poisson.jl:95-97,190-191
 __global__ void k_shift_norms(GridX g, float* __restrict__ r, const double* __restrict__ sum, double n_inside, double* __restrict__ part, float* __restrict__ pmax) {
@@ -843,16 +843,16 @@ int jacobi_pp_shift(float* rout, const float* r, float* x, const GridX& g, float
   const int zc = wl_march_chunk(g, g.k1 - g.k0);
   dim3 grid = wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc));
   const double ni = (double)wl_ninside_global(wl_grid{g.D, g.nx, g.ny, g.nz, g.k0, g.k1, g.gk, g.gnz});
-  hipLaunchKernelGGL(k_jacobi_march_cl<1>, grid, dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc, (const double*)(ws.res_d + 0), ni, ws.pa, ws.pm);
+  hipLaunchKernelGGL(k_jacobi_march_cl<1>, grid, dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc, (const double*)(ws.res_d + 0), ni, ws.pa, ws.pm, 0);
   hipLaunchKernelGGL(k_final_sum_max, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, ws.pm, (int)grid.x, ws.res_d + slot_d, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
-int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s) {
+int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float* Dg, const float* iD, const GridX& g, float w, const ConstL& cl, hipStream_t s, int xzero) {
   if (cl.on && g.D == 3 && g_jacobi_march) {
     const int zc = wl_march_chunk(g, g.k1 - g.k0);
-    hipLaunchKernelGGL(k_jacobi_march_cl<0>, wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc)), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc, (const double*)nullptr, 0.0, (double*)nullptr, (float*)nullptr);
-  } else if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl);
-  else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w);
+    hipLaunchKernelGGL(k_jacobi_march_cl<0>, wl_plane_grid(g, wl_march_slots(g.k1 - g.k0, zc)), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, zc, (const double*)nullptr, 0.0, (double*)nullptr, (float*)nullptr, xzero);
+  } else if (cl.on) DSEL(g.D, k_jacobi_pp_cl, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, w, cl, xzero);
+  else DSEL(g.D, k_jacobi_pp, wl_plane_grid(g, g.k1 - g.k0), dim3(WL_BLOCK), 0, s, g, rout, r, x, L, Dg, iD, w, xzero);
   WL_LAUNCH_CHECK(); return 0;
 }
 // if (levels below `first` exist) Vcycle!(first); smooth!(first)  — for the levels handed over in `lv` (coarsening flags in lv[l].c*)

@@ -581,6 +581,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "store_eps") { s->mg->store_eps = value != 0; return 0; }
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
+  if (n == "skip_fill") { s->mg->skip_fill = value != 0; return 0; }
   if (n == "defer_shift") { s->mg->defer_shift = value != 0; return 0; }
   if (n == "zsplit") { s->mg->use_zsplit = value != 0; s->mg->zsplit_min = value == 2 ? 0 : 32L << 20; return 0; }   // 2: on levels of any size (needs update!)
   if (n == "hybrid") { s->use_hybrid = value != 0; return 0; }
