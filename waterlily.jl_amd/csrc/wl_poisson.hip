@@ -213,7 +213,11 @@ __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __
   if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
 }
 __global__ void k_fin_max2(const float* __restrict__ pmax, int n, float* __restrict__ om) {
-  float mx = -INFINITY; for (int q = threadIdx.x; q < n; q += WL_BLOCK) mx = fmaxf(mx, pmax[q]);
+  float mx = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+  int q = threadIdx.x;
+  for (; q + 3 * WL_BLOCK < n; q += 4 * WL_BLOCK) { mx = fmaxf(mx, pmax[q]); m1 = fmaxf(m1, pmax[q + WL_BLOCK]); m2 = fmaxf(m2, pmax[q + 2 * WL_BLOCK]); m3 = fmaxf(m3, pmax[q + 3 * WL_BLOCK]); }
+  for (; q < n; q += WL_BLOCK) mx = fmaxf(mx, pmax[q]);
+  mx = fmaxf(fmaxf(mx, m1), fmaxf(m2, m3));
   mx = block_max(mx); if (threadIdx.x == 0) *om = mx;
 }
 // exact test of the constant-coefficient pattern over EVERY cell of L (ghosts included): L[I,a] == (I_a ∈ {1,2,N_a} ? 0 : c_a)
@@ -280,15 +284,26 @@ __global__ void k_plane_bad(GridX g, const float* __restrict__ L, float c0, floa
   for (int a = 0; a < D; a++) if (L[(long)a * g.cs + o] != ((I[a] <= 2 || I[a] >= N[a]) ? 0.f : c[a])) bad[k] = 1;
 }
 // deterministic second stage: res_d[slot] = Σ partials
+// (single-workgroup final stages: four independent accumulators per thread keep four loads in flight — with up to ≈18 000 partials
+//  of the marching kernels the dependent one-load-at-a-time loop took 18–27 µs)
 __global__ void k_final_sum(const double* __restrict__ part, int n, double* __restrict__ out) {
-  double a = 0.0;
-  for (int q = threadIdx.x; q < n; q += WL_BLOCK) a += part[q];
+  double a = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int q = threadIdx.x;
+  for (; q + 3 * WL_BLOCK < n; q += 4 * WL_BLOCK) { a += part[q]; a1 += part[q + WL_BLOCK]; a2 += part[q + 2 * WL_BLOCK]; a3 += part[q + 3 * WL_BLOCK]; }
+  for (; q < n; q += WL_BLOCK) a += part[q];
+  a = (a + a1) + (a2 + a3);
   a = block_sum(a);
   if (threadIdx.x == 0) *out = a;
 }
 __global__ void k_final_sum_max(const double* __restrict__ part, const float* __restrict__ pmax, int n, double* __restrict__ out_s, float* __restrict__ out_m) {
-  double a = 0.0; float mx = -INFINITY;
-  for (int q = threadIdx.x; q < n; q += WL_BLOCK) { a += part[q]; mx = fmaxf(mx, pmax[q]); }
+  double a = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; float mx = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+  int q = threadIdx.x;
+  for (; q + 3 * WL_BLOCK < n; q += 4 * WL_BLOCK) {
+    a += part[q]; a1 += part[q + WL_BLOCK]; a2 += part[q + 2 * WL_BLOCK]; a3 += part[q + 3 * WL_BLOCK];
+    mx = fmaxf(mx, pmax[q]); m1 = fmaxf(m1, pmax[q + WL_BLOCK]); m2 = fmaxf(m2, pmax[q + 2 * WL_BLOCK]); m3 = fmaxf(m3, pmax[q + 3 * WL_BLOCK]);
+  }
+  for (; q < n; q += WL_BLOCK) { a += part[q]; mx = fmaxf(mx, pmax[q]); }
+  a = (a + a1) + (a2 + a3); mx = fmaxf(fmaxf(mx, m1), fmaxf(m2, m3));
   a = block_sum(a);
   mx = block_max(mx);
   if (threadIdx.x == 0) { *out_s = a; *out_m = mx; }
