@@ -175,7 +175,7 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    "store_f"[0] materialise the intermediates f, z          "store_eps"[0] materialise the smoother's final ϵ
    "overlap"[1] u exchange on a second stream (slabs)       "convz"[0], "convm"[0] alternative conv_diff! kernels (slower)
    "jacobi_march"[1] z-marching constant-coefficient Jacobi  "farmask"[1], "hybrid"[1] BDIM! fast paths away from a body
-   "zsplit"[1] pair smoother on the planes away from a body (levels >= 32 M cells; 2: any size)
+   "zsplit"[1] pair smoother on the planes away from a body (levels >= 16 M cells; 2: any size, v >= 4: >= v·2^20 cells)
    "defer_shift"[1] residual!'s mean shift + solver!'s first norms folded into the finest level's z-marching Jacobi!
    "skip_fill"[1] Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi! */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);

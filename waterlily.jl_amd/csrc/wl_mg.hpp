@@ -26,7 +26,7 @@ struct wl_mg {
   bool store_eps = true;    // the blocked smoother also stores the final ϵ (p.ϵ of the reference); the mom_step! composite turns it off
   bool use_fused = true;    // temporally blocked GaussSeidelRB! on eligible levels (wl_fused.hip)
   bool use_zsplit = true;   // body levels: constant-coefficient pair kernels on the planes away from the body, general kernels on the rest
-  long zsplit_min = 32L << 20;   // ... on levels of at least this many cells (smaller ranges do not fill 256 CUs: 256³ loses 4 %, 384³ gains 4 %, 512³ 7 %)
+  long zsplit_min = 16L << 20;   // ... on levels of at least this many cells (smaller ranges do not fill 256 CUs; with the 16-row pair tiles a 256³ level gains 2 %, 384³ 4 %, 512³ 7 %; 128³ levels lose)
   bool skip_fill = true;    // Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi! (x = ω·ϵ instead of x += ω·ϵ)
   bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
   bool shift_pending = false;

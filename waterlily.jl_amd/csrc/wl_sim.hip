@@ -583,7 +583,9 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
   if (n == "skip_fill") { s->mg->skip_fill = value != 0; return 0; }
   if (n == "defer_shift") { s->mg->defer_shift = value != 0; return 0; }
-  if (n == "zsplit") { s->mg->use_zsplit = value != 0; s->mg->zsplit_min = value == 2 ? 0 : 32L << 20; return 0; }   // 2: on levels of any size (needs update!)
+  if (n == "zsplit") {   // 0 off, 1 default size gate, 2 levels of any size, v >= 4: levels of at least v·2^20 cells (takes effect at the next update!)
+    s->mg->use_zsplit = value != 0; s->mg->zsplit_min = value == 2 ? 0 : (value >= 4 ? (long)value << 20 : 16L << 20); return 0;
+  }
   if (n == "hybrid") { s->use_hybrid = value != 0; return 0; }
   if (n == "farmask") { s->use_farmask = value != 0; return 0; }
   if (n == "store_f") { s->store_f = value != 0; return 0; }
