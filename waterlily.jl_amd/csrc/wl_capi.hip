@@ -192,14 +192,20 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     }
     {
       ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s);
+      // L₁/L∞ of the new residual: every range leaves its own pair in a slot of its own (res_d[2|5|6], res_f[1|2|3]); solver! adds them
+      static const int SD[3] = {2, 5, 6}, SF[3] = {1, 2, 3};
+      norm_slots = 0;
       for (int i = 0; i < 3; i++) if (parts[i].b > parts[i].a) {
         const GridX g = sub(parts[i].a, parts[i].b);
-        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nullptr, 2, 1, *parts[i].cl, s));
-        else WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, g, w, nullptr, 2, 1, *parts[i].cl, s));
+        const RedWs* nws = want_norms ? &ws : nullptr;
+        if (want_norms) norm_slots |= 1 << i;
+        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s));
+        else WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s));
       }
     }
     if (!pro) std::swap(p.r, p.rs);
-    return 0;        // (the norms of the new residual are left to the caller: norms_done stays false)
+    if (norms_done) *norms_done = want_norms;
+    return 0;
   }
   if (fused) {   // two z-marching kernels instead of six passes (+ the pending prolongation as an extra stage of kernel A)
     const RedWs* nws = want_norms ? &ws : nullptr;
@@ -226,6 +232,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
       { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
       std::swap(p.r, p.rs);
     }
+    norm_slots = 0;
     if (norms_done) *norms_done = want_norms;
     return 0;
   }
@@ -319,7 +326,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     shift_pending = defer_shift && itmx >= 1 && !(comm && comm->size > 1) && !perdir && lv.size() > 1 && wl::jacobi_takes_shift(p.x_, p.cl);
     if (!shift_pending) WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));
   }
-  double hd[3]; float hf[2];
+  double hd[7]; float hf[4];
   float w = 1.f;
   // r₁ of the initial residual is only needed for the ω rule after the first V-cycle: fetched with the first iteration's norms
   bool have_r1 = false; float r1 = 0.f, rinf = 0.f;
@@ -328,10 +335,17 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
   while (np < itmx) {
     WL_TRY(vcycle(0, w, s, true));
     bool nd = false;
+    norm_slots = 0;
     WL_TRY(smooth(0, 4, w, s, true, &nd));                                                // fused path: norms come out of kernel B
-    if (!nd) WL_TRY(wl::norms_dev(lv[0].r, p.x_, ws, 2, 1, s));                           // rnew -> res_d[2], r∞ -> res_f[1]
+    if (!nd) { norm_slots = 0; WL_TRY(wl::norms_dev(lv[0].r, p.x_, ws, 2, 1, s)); }       // rnew -> res_d[2], r∞ -> res_f[1]
     WL_TRY(wl::combine_results(comm, ws, s));                                             // (slot 0 becomes P·Σr: not used again)
-    WL_TRY(wl::read_results(ws, hd, 3, hf, 2, s));
+    WL_TRY(wl::read_results(ws, hd, 7, hf, 4, s));
+    if (norm_slots) {   // z-split smoother: one (L₁, L∞) pair per plane range
+      static const int SD[3] = {2, 5, 6}, SF[3] = {1, 2, 3};
+      double a = 0.0; float m = 0.f;
+      for (int i = 0; i < 3; i++) if (norm_slots & (1 << i)) { a += hd[SD[i]]; m = std::fmax(m, hf[SF[i]]); }
+      hd[2] = a; hf[1] = m;
+    }
     if (!have_r1) { r1 = (float)hd[1]; log_r1.push_back(hd[1]); log_rinf.push_back(hf[0]); log_w.push_back(1.0); have_r1 = true; }
     const float rnew = (float)hd[2]; rinf = hf[1]; np++;
     log_r1.push_back((double)rnew); log_rinf.push_back((double)rinf); log_w.push_back((double)w);
