@@ -276,6 +276,16 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
     if (!perdir && (!fine.dist || fine.cl.on)) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
       WL_TRY(halo(fine, fine.r, 1, s));              // (slab: ϵ=r·iD of the neighbour's boundary plane is recomputed from its r; iD is evaluated from the position)
       if (l == 0 && shift_pending) { shift_pending = false; WL_TRY(wl::jacobi_pp_shift(fine.eps, fine.r, fine.x, fine.x_, 1.f, fine.cl, ws, 1, 0, s)); }
+      else if (fine.part && use_zsplit && !fine.dist) {
+        // level with a body: constant-coefficient (z-marching) Jacobi on the plane ranges away from it, the general kernel around it —
+        // same ranges as the z-split smoother (the output is a separate array, r is read across the cuts)
+        const int xz = fine.xzero ? 1 : 0; fine.xzero = false;
+        const int m = 4, na = std::max(fine.g.k0, fine.za - m), nb = std::min(fine.g.k1, fine.zb + m + 1);
+        auto sub = [&](int a, int b) { GridX g = fine.x_; g.k0 = a; g.k1 = b; return g; };
+        if (nb > na) WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, sub(na, nb), 1.f, fine.cl, s, xz));
+        if (na > fine.g.k0) WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, sub(fine.g.k0, na), 1.f, fine.clp, s, xz));
+        if (fine.g.k1 > nb) WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, sub(nb, fine.g.k1), 1.f, fine.clp, s, xz));
+      }
       else { const int xz = fine.xzero ? 1 : 0; fine.xzero = false; WL_TRY(wl::jacobi_pp(fine.eps, fine.r, fine.x, fine.L, fine.D, fine.iD, fine.x_, 1.f, fine.cl, s, xz)); }
       std::swap(fine.r, fine.eps);
     } else {
