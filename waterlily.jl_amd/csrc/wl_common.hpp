@@ -236,6 +236,8 @@ int residual(float* r, const float* x, const float* z, const float* L, const flo
 int residual_part(float* r, const float* x, const float* z, const float* L, const float* D, const float* iD, const GridX& g, const RedWs& ws, hipStream_t s);
 int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s);
 int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s);
+int div_residual_split(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws,
+                       const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s);
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s);
 // computes L₁/L∞ of r into ws.res_d[slot_d], ws.res_f[slot_f] (device) — ghosts of r are zero by construction

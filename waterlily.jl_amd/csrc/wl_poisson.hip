@@ -76,14 +76,15 @@ __global__ void k_residual(GridX g, float* __restrict__ r, const float* __restri
 // x_out ≠ x (neighbours still read the unscaled x; x·dt of a neighbour is recomputed — the same product bit for bit).
 template <int D, int CL>
 __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict__ xout, float* __restrict__ r, const float* __restrict__ x, const float* __restrict__ u,
-                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part, wl::ConstL cl, int zchunk) {
+                               const float* __restrict__ L, const float* __restrict__ Dg, const float* __restrict__ iD, float dt, double* __restrict__ part, wl::ConstL cl, int zchunk,
+                               int p0, int p1) {      // the launch covers the local planes [p0,p1) (all of them: 0, g.nz)
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   double acc = 0.0;
   if (cell_ij(g, m, i, j)) {
     const bool inij = interior_ij(g, i, j);
     // this slot marches over planes [ks,ke): x[k-1], x[k], x[k+1] and u_z[k], u_z[k+1] live in registers
-    const int ks = pz * zchunk, ke = (ks + zchunk < g.nz) ? ks + zchunk : g.nz;
+    const int ks = p0 + pz * zchunk, ke = (ks + zchunk < p1) ? ks + zchunk : p1;
     long o = m + (long)ks * g.sz;
     float xkm = (D == 3 && ks > 0) ? x[o - g.sz] : 0.f, xk = (ks < ke) ? x[o] : 0.f;
     float uzk = (D == 3 && inij && ks < ke) ? u[2 * g.cs + o] : 0.f;
@@ -747,8 +748,27 @@ int residual_part(float* r, const float* x, const float* z, const float* L, cons
 int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* Dg, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s) {
   const int zc = wl_march_chunk(g, g.nz);
   dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
-  DSEL2(g.D, cl.on, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa, cl, zc);
+  DSEL2(g.D, cl.on, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa, cl, zc, 0, g.nz);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)grid.x, ws.res_d + 0);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// The same on a level with a body: the local planes [0,na) and [nb,nz) follow the constant-coefficient pattern `far` (coefficients from
+// the position), the planes [na,nb) around the body read L.  Three launches, their partial sums side by side, one final sum.
+int div_residual_split(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* Dg, const float* iD, const GridX& g, float dt, const RedWs& ws,
+                       const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s) {
+  const int lo[3] = {0, na, nb}, hi[3] = {na, nb, g.nz};
+  int off = 0;
+  for (int q = 0; q < 3; q++) {
+    const int np = hi[q] - lo[q];
+    if (np <= 0) continue;
+    const ConstL& cl = q == 1 ? near : far;
+    const int zc = wl_march_chunk(g, np);
+    dim3 grid = wl_plane_grid(g, wl_march_slots(np, zc));
+    if (off + (int)grid.x > WL_MAXPART) { wl_set_error("div_residual_split: too many partial sums"); return WL_EINVAL; }
+    DSEL2(g.D, cl.on, k_div_residual, grid, dim3(WL_BLOCK), 0, s, g, z, xout, r, x, u, L, Dg, iD, dt, ws.pa + off, cl, zc, lo[q], hi[q]);
+    off += (int)grid.x;
+  }
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, off, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s) {

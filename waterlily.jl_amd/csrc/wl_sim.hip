@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "wl_common.hpp"
+#include <algorithm>
 #include "wl_mg.hpp"
 
 namespace {
@@ -414,7 +415,13 @@ struct wl_sim {
       WL_TRY(wl::bc_per_scalar(p, G, d.perdir_mask, s));                                   // residual!: perBC!(x) :93 (copies commute with the scaling)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
-      { ProfScope pr(WL_PROF_RESIDUAL, s); WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s)); }
+      {
+        ProfScope pr(WL_PROF_RESIDUAL, s);
+        if (l0.part && mg->use_zsplit && !comm) {   // a body: coefficients from the position on the plane ranges away from it (as in smooth!)
+          const int m = 4, na = std::max(l0.g.k0, l0.za - m), nb = std::min(l0.g.k1, l0.zb + m + 1);
+          WL_TRY(wl::div_residual_split(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, l0.clp, na, nb, s));
+        } else WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s));
+      }
       std::swap(p, ps); l0.x = p;
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
