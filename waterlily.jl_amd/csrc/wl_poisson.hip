@@ -136,12 +136,13 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
 }
 // mom_project! tail (src/Flow.jl:227-230): u[I,i] -= L[I,i]·∂ᵢx ; p_out = x/dt (ALL cells), p_out ≠ x
 template <int D, int CL>
-__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl, int zchunk) {
+__global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl, int zchunk,
+                                  int p0, int p1) {   // local planes [p0,p1) of this launch
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
   const bool inij = interior_ij(g, i, j);
-  const int ks = pz * zchunk, ke = (ks + zchunk < g.nz) ? ks + zchunk : g.nz;
+  const int ks = p0 + pz * zchunk, ke = (ks + zchunk < p1) ? ks + zchunk : p1;
   long o = m + (long)ks * g.sz;
   float xkm = (D == 3 && ks > 0 && ks < ke) ? x[o - g.sz] : 0.f;      // x[k-1] stays in a register while marching
   const float lxc = CL ? wl::wl_cl_coef(i + 1, g.nx, cl.c[0]) : 0.f, lyc = CL ? wl::wl_cl_coef(j + 1, g.ny, cl.c[1]) : 0.f;
@@ -166,13 +167,13 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
 // (non-periodic, no exitBC).  Cells outside the interior of u_out are left for BC! to write.
 template <int D, int CL>
 __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout,
-                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax) {
+                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   float mx = -INFINITY;
   if (cell_ij(g, m, i, j)) {
     const bool inij = interior_ij(g, i, j);
-    const int ks = pz * zchunk, ke = (ks + zchunk < g.nz) ? ks + zchunk : g.nz;
+    const int ks = p0 + pz * zchunk, ke = (ks + zchunk < p1) ? ks + zchunk : p1;
     long o = m + (long)ks * g.sz;
     float xkm = (D == 3 && ks > 0 && ks < ke) ? x[o - g.sz] : 0.f, xc = (ks < ke) ? x[o] : 0.f;
     float lx = 0.f, lxp = 0.f, ly = 0.f, lyp = 0.f;
@@ -773,7 +774,19 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
 }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s) {
   const int zc = wl_march_chunk(g, g.nz);
-  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc);
+  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, 0, g.nz);
+  WL_LAUNCH_CHECK(); return 0;
+}
+// level with a body: planes [0,na) and [nb,nz) with the constant-coefficient pattern `far`, [na,nb) reading L (see div_residual_split)
+int project_unscale_split(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s) {
+  const int lo[3] = {0, na, nb}, hi[3] = {na, nb, g.nz};
+  for (int q = 0; q < 3; q++) {
+    const int np = hi[q] - lo[q];
+    if (np <= 0) continue;
+    const ConstL& cl = q == 1 ? near : far;
+    const int zc = wl_march_chunk(g, np);
+    DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(np, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, lo[q], hi[q]);
+  }
   WL_LAUNCH_CHECK(); return 0;
 }
 // projection tail + CFL's σ and max(σ) -> ws.res_f[slot_f]; u_out must not alias u_in
@@ -783,8 +796,28 @@ int project_cfl(float* uout, const float* uin, const float* L, const float* x, f
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   const int zc = wl_march_chunk(g, g.nz);
   const dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
-  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm);
+  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz);
   hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
+  WL_LAUNCH_CHECK(); return 0;
+}
+int project_cfl_split(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& near, const ConstL& far,
+                      int na, int nb, const RedWs& ws, int slot_f, hipStream_t s) {
+  if (uout == uin) { wl_set_error("project_cfl: output aliases input"); return WL_EINVAL; }
+  int kfirst = 0, klast = 1;
+  if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  const int lo[3] = {0, na, nb}, hi[3] = {na, nb, g.nz};
+  int off = 0;
+  for (int q = 0; q < 3; q++) {
+    const int np = hi[q] - lo[q];
+    if (np <= 0) continue;
+    const ConstL& cl = q == 1 ? near : far;
+    const int zc = wl_march_chunk(g, np);
+    const dim3 grid = wl_plane_grid(g, wl_march_slots(np, zc));
+    if (off + (int)grid.x > WL_MAXPART) { wl_set_error("project_cfl_split: too many partial maxima"); return WL_EINVAL; }
+    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q]);
+    off += (int)grid.x;
+  }
+  hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, off, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 // host-synchronising (update! time only): reads one interior face value per component, then verifies the whole array on device

@@ -425,11 +425,15 @@ struct wl_sim {
       std::swap(p, ps); l0.x = p;
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
+      const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
+      const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
       if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
-        WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s));
+        if (split) WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s));
+        else WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s));
         WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
         std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
-      } else WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
+      } else if (split) WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s));
+      else WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
       std::swap(p, ps); l0.x = p;
       return bc_u(s);
     }
