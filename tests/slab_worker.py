@@ -64,6 +64,12 @@ def main():
             for k in range(1 + r * nc, 1 + (r + 1) * nc):
                 assert np.all(full[:, :, k, :] == 1000 * k + r + 1)
         assert np.all(full[:, :, 0, :] == 0) and np.all(full[:, :, -1, :] == 0)
+        # the communicator's counters (wl_comm_stats): two exchanges (depth 1 and 2) of ncomp planes to each existing neighbour, two gathers
+        st = slab.comm_stats(comm)
+        nb = (1 if rank > 0 else 0) + (1 if rank < size - 1 else 0)
+        plane = g.nx * g.ny * 4
+        assert st["halo_exchanges"] == 2 and st["plane_allgathers"] == 2 and st["scalar_combines"] == 0, st
+        assert st["halo_bytes_sent"] == (1 + 2) * plane * ncomp * nb, st
         comm.destroy()
         print(f"rank {rank}: cpu_halo ok", flush=True)
     elif mode == "gpu_sim":
