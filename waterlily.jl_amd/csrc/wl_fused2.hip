@@ -50,7 +50,8 @@ static bool rows16(const GridX& g) {
   // measured: 256³ levels gain (A+B 0.28 -> 0.24 ms), 512³ loses (B 0.72 -> 0.80 ms), 128³ and below lose slightly
   const long tiles32 = (long)((g.nx + 55) / 56) * ((g.ny + 25) / 26);
   const long rounds32 = tiles32 * ((g.k1 - g.k0 + 31) / 32);
-  return rounds32 >= 128 && rounds32 < 2048;
+  // (in-plane size decides first: a 512² plane has 200 tiles of 64×32 cells — enough parallelism per plane layer, also on a z-slab of few planes)
+  return tiles32 >= 24 && tiles32 < 128 && rounds32 >= 128 && rounds32 < 2048;
 }
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s) {
   return rows16(g) ? pair16::gsrb_pair_A(emid, r, g, cl, s) : pair32::gsrb_pair_A(emid, r, g, cl, s);
