@@ -37,11 +37,49 @@ BYTES_KERNEL = {
 }
 
 
-def cpu_baseline(n=128, warm=2, steps=None, budget_s=12.0):
-    """Time the oracle (CPU restatement, OpenMP = analogue of the reference's KA CPU threads) on the same
-    TGV workload at 128³.  Bounded: stops after `budget_s` seconds of timed work."""
+def _oracle_tgv(orc, n, omp):
+    """the bench workload (wall-bounded TGV) on the oracle at n³"""
     import math
     import numpy as np
+    sim = orc.Simulation((n, n, n), (0, 0, 0), n, U=1, nu=n / 1600.0, T=np.float32, omp=omp)
+    kap = math.pi / n
+    u = sim.u
+    ax = (np.arange(n + 2, dtype=np.float64) - 0.5)                                # loc(0,I) per axis (0-based array index − 0.5)
+    cx, cy, cz = np.cos(kap * ax), np.cos(kap * ax), np.cos(kap * ax)
+    sxh, syh = np.sin(kap * (ax - 0.5)), np.sin(kap * (ax - 0.5))
+    u[..., 0] = (-sxh[:, None, None] * cy[None, :, None] * cz[None, None, :]).astype(np.float32)
+    u[..., 1] = (cx[:, None, None] * syh[None, :, None] * cz[None, None, :]).astype(np.float32)
+    u[..., 2] = 0
+    orc.BC(u, (0, 0, 0))
+    sim.field("u0")[...] = u
+    return sim
+
+
+def _time_oracle(orc, L, n, threads, warm, budget_s, max_steps=400):
+    import numpy as np
+    L.wlo_set_threads(threads)
+    sim = _oracle_tgv(orc, n, omp=True)
+    for _ in range(warm):
+        sim.step(remeasure=False)
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        sim.step(remeasure=False)
+        k += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or k >= max_steps:
+            break
+    nmean = float(np.mean(sim.pois_n[2 * warm:]))
+    return {"value": n**3 * k / el, "unit": "cells*steps/s", "cores": int(threads), "kind": "port",
+            "sample": f"3D TGV {n}^3 f32, {k} mom_step! after {warm} warm-up, {'serial (1 thread)' if threads == 1 else f'OpenMP over {threads} threads'}, mean pois.n={nmean:.2f}",
+            "seconds": el}
+
+
+def cpu_baseline(budget_s=12.0):
+    """Time the oracle (CPU restatement of the reference algorithm, kind "port") on the bench workload on this box's host
+    cores, SURVEY §8d: (i) serial — the analogue of the reference's backend="SIMD" loops (src/core.jl:146-155) — at 128³,
+    (ii) all cores (one OpenMP parallel-for per @loop, the analogue of the KA CPU backend) at 128³ and, budget permitting, 256³.
+    `value` is the all-core figure at the largest size that ran; the others sit beside it.  Bounded to ≈ 2·budget_s."""
     from oracle import oracle as orc
     orc.build()
     L = orc.lib(omp=True)
@@ -54,33 +92,19 @@ def cpu_baseline(n=128, warm=2, steps=None, budget_s=12.0):
     except Exception:
         pass
     cores = int(os.environ.get("WL_CPU_THREADS", cores))
+    serial = _time_oracle(orc, L, 128, 1, 1, budget_s * 0.4, max_steps=12)
+    omp128 = _time_oracle(orc, L, 128, cores, 2, budget_s * 0.5)
+    out = dict(omp128)
+    # 256³ fits the budget when a step takes < budget/6 at the 128³ rate (8× the cells)
+    if cores > 1 and 256**3 / omp128["value"] * 6 < budget_s * 1.1:
+        try:
+            out = _time_oracle(orc, L, 256, cores, 1, budget_s * 0.6, max_steps=12)
+            out["omp_128"] = omp128
+        except MemoryError:
+            pass
+    out["serial"] = serial
     L.wlo_set_threads(cores)
-    sim = orc.Simulation((n, n, n), (0, 0, 0), n, U=1, nu=n / 1600.0, T=np.float32, omp=True)
-    kap = math.pi / n
-    u = sim.u
-    ax = np.arange(n + 2, dtype=np.float32) + np.float32(1) - np.float32(1.5)     # loc(0,I) per axis
-    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
-    h = np.float32(0.5)
-    u[..., 0] = (-np.sin(kap * (X - h).astype(np.float64)) * np.cos(kap * Y.astype(np.float64)) * np.cos(kap * Z.astype(np.float64))).astype(np.float32)
-    u[..., 1] = (np.cos(kap * X.astype(np.float64)) * np.sin(kap * (Y - h).astype(np.float64)) * np.cos(kap * Z.astype(np.float64))).astype(np.float32)
-    u[..., 2] = 0
-    orc.BC(u, (0, 0, 0))
-    sim.field("u0")[...] = u
-    for _ in range(warm):
-        sim.step(remeasure=False)
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        sim.step(remeasure=False)
-        k += 1
-        el = time.perf_counter() - t0
-        if (steps is not None and k >= steps) or (steps is None and el >= budget_s) or k >= 400:
-            break
-    el = time.perf_counter() - t0
-    nmean = float(np.mean(sim.pois_n[2 * warm:]))
-    return {"value": n**3 * k / el, "unit": "cells*steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"3D TGV {n}^3 f32, {k} mom_step! after {warm} warm-up, OpenMP over {cores} threads, mean pois.n={nmean:.2f}",
-            "seconds": el}
+    return out
 
 
 def read_prof(lib):
@@ -96,8 +120,26 @@ def read_prof(lib):
     return prof
 
 
+KERNEL_CONFIG_FILES = ("wl_fused2_body.inc", "wl_fused2.hip", "wl_fused.hip", "wl_common.hpp")
+
+
+def kernel_config_sha():
+    """identity of the smoother kernels' sources: a PMC traffic figure is only quoted beside a timing of the SAME kernels"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_CONFIG_FILES:
+        with open(os.path.join(ROOT, "waterlily.jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
-    """`roofline` object for the finest-level smooth! of THIS rank (ncell = the cells its launches process)"""
+    """`roofline` object for the finest-level smooth! of THIS rank (ncell = the cells its launches process).
+
+    achieved / frac   : the kernels' OWN algorithmic bytes (what each launch must move, BYTES_KERNEL) ÷ HIP-event time ÷ 8 TB/s
+    traffic(_frac)    : HBM bytes from the PMC counters (2·FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes) of the same kernel sources, else null
+    op_equivalent     : SURVEY §8d's per-OPERATION bytes (GaussSeidelRB! 40 + prolongate!/increment! 36.5 B/cell — what the reference's
+                        own formulation would have to move for the work these kernels do) ÷ the same time: a speed-up figure, not a bandwidth."""
     # The roofline kernel: the finest-level smooth! (GaussSeidelRB!, it=4) as executed — the temporally blocked kernel pair A+B.
     if not prof["gsrb_B"]["launches"]:   # experiments with the blocked smoother switched off: report the plain colour sweep instead
         prof["gsrb_B"], prof["gsrb_A"] = prof["gs_sweep"], prof["gs_sweep"]
@@ -113,24 +155,26 @@ def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
     if use_traffic and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("size") == N and {"A", "B"} <= set(tj.get("kernels", {})):
+            if tj.get("size") == N and {"A", "B"} <= set(tj.get("kernels", {})) and tj.get("kernel_config_sha") == kernel_config_sha():
                 tper = {k: v["hbm_bytes_per_launch"] for k, v in tj["kernels"].items()}
                 traffic, tsrc = tper["A"] + tper["B"], tj.get("source")
         except Exception:
             pass
     kname = {2: "k_gsrb2_A + k_gsrb2_B (wl_fused2.hip, pair kernels)", 1: "k_gsrb_A + k_gsrb_B (wl_fused.hip)", 0: "k_gs_sweep passes"}[kind0]
+    own = bytes_a + bytes_b
     roof = {
         "bound": "hbm",
         "kernel": f"finest-level smooth! = GaussSeidelRB!(it=4) (src/Poisson.jl:141-148){' + the V-cycle prolongate!+increment! (src/MultiLevelPoisson.jl:99-100)' if pro_fused else ''}, executed as {kname}",
-        # SURVEY §8d's per-operation figure × cells ÷ HIP-event duration of the kernel pair (measured live, launch stream)
-        "achieved": gbs(bytes_op, pair_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(bytes_op, pair_ms) / HBM_PEAK_GBS,
+        "achieved": gbs(own, pair_ms), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs(own, pair_ms) / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": tsrc,
-        "bytes_per_cell": bytes_op, "bytes_definition": "reference-defined operation bytes (SURVEY §8d): GaussSeidelRB! 40"
-                          + (" + prolongate!/increment! 36.5" if pro_fused else "") + " B/cell; the kernels move fewer (see kernels.*)",
+        "traffic_frac": (traffic / (pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+        "bytes_per_cell": own, "bytes_definition": "the kernels' own algorithmic bytes per interior cell and launch pair (distinct elements each launch must read + write; "
+                          "L, D, iD are evaluated from the cell position on constant-coefficient levels) — see kernels.*",
         "avg_launch_ms": pair_ms, "launches": prof["gsrb_B"]["launches"],
         "constant_coefficient_kernels": const0,
-        "own_bytes": {"bytes_per_cell": bytes_a + bytes_b, "achieved": gbs(bytes_a + bytes_b, pair_ms), "frac": gbs(bytes_a + bytes_b, pair_ms) / HBM_PEAK_GBS,
-                      "what": "bytes the kernel pair itself must move (its own algorithmic minimum) ÷ the same time"},
+        "op_equivalent": {"bytes_per_cell": bytes_op, "achieved": gbs(bytes_op, pair_ms), "frac": gbs(bytes_op, pair_ms) / HBM_PEAK_GBS,
+                          "what": "reference-defined operation bytes (SURVEY §8d: GaussSeidelRB! 40" + (" + prolongate!/increment! 36.5" if pro_fused else "")
+                                  + " B/cell) ÷ the same time — the rate the reference's formulation would need for this work; NOT bytes moved"},
         "kernels": {
             "A": {"what": ("prolongate!+increment! + eps=r*iD + colour sweeps 1,2" if pro_fused else "eps=r*iD + colour sweeps 1,2"),
                   "bytes_per_cell": bytes_a, "avg_ms": ka_ms, "achieved": gbs(bytes_a, ka_ms), "frac": gbs(bytes_a, ka_ms) / HBM_PEAK_GBS,
@@ -141,6 +185,22 @@ def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
         },
     }
     return roof
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) through torch.distributed.run and relay
+    their output; rank 0 prints the JSON line.  Called before this process imports torch or touches the GPU; the children are fresh
+    processes (no exec of a GPU-initialised process)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -155,14 +215,35 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or run without a launcher)")
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("WL_BENCH_DRY"):
+        # launcher rehearsal without a GPU (CPU test of the --gpus N contract): rendezvous over gloo, count the ranks, rank 0 prints a line
+        import torch
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group(backend="gloo")
+            t = torch.ones(1)
+            dist.all_reduce(t)
+            nr = int(t.item())
+            dist.destroy_process_group()
+        else:
+            nr = 1
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": nr, "steps": args.steps, "warmup": args.warmup, "size": args.size}), flush=True)
+        return
+    import torch
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if os.environ.get("WL_BENCH_ONE_GPU"):      # rehearsal of the multi-rank path on a one-GPU box (with WL_DIST_BACKEND=gloo)
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} devices, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     import waterlily_jl_amd as w
     from waterlily_jl_amd._lib import check
@@ -172,7 +253,8 @@ def main():
     N = args.size
     if world > 1:
         from waterlily_jl_amd import slab
-        return slab.bench_main(args, world, rank, local_rank, read_prof=read_prof, build_roofline=build_roofline)
+        return slab.bench_main(args, world, rank, local_rank, read_prof=read_prof, build_roofline=build_roofline,
+                               cpu_baseline=None if args.no_cpu_baseline else (lambda: cpu_baseline(budget_s=args.cpu_budget)))
 
     sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
     for key, val in os.environ.items():      # A/B switches for experiments: WL_OPT_<option of wl_sim_set_option>=0/1 (defaults: fast paths on)

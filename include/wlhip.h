@@ -231,7 +231,19 @@ typedef int (*wl_sendrecv_fn)(void* ctx, const void* send_lo, void* recv_lo, con
 typedef int (*wl_allgather_fn)(void* ctx, const void* send, void* recv, size_t bytes_each, void* stream);
 int wl_comm_rccl_unique_id(char out128[128]);
 int wl_comm_rccl_create(wl_comm** out, int rank, int size, const char uid128[128]);
+/* 1 when librccl.so.1 and every entry point used here resolved (ranks agree on this BEFORE anyone calls ncclCommInitRank) */
+int wl_comm_rccl_available(void);
+/* second communicator (its own unique id) for the exchanges that run on the communicator's own HIP stream, overlapped with
+ * stencil work: one ncclComm_t is then only ever used from one stream.  Collective: every rank calls it, after _create. */
+int wl_comm_rccl_add_async(wl_comm* c, const char uid128[128]);
 int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_sendrecv_fn sendrecv, wl_allgather_fn allgather);
+/* TEST mode of a ONE-rank communicator: both neighbours are this rank (z-periodic wrap onto itself), so that the transport
+ * calls a one-rank run would skip (ncclSend/ncclRecv groups, in-place ncclAllGather, the scalar combine) execute on a one-GPU box */
+int wl_comm_set_loopback(wl_comm* c, int on);
+/* test hooks: the overlapped exchange (begin on the communicator's stream + wait) and the device-side scalar combine
+ * (d8/f8: one 128-byte device record, 8 doubles then 8 floats; Σ / max over ranks in place) */
+int wl_comm_halo_async(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* stream);
+int wl_comm_combine_test(wl_comm* c, double* d8, float* f8, void* stream);
 int wl_comm_destroy(wl_comm* c);
 int wl_comm_rank(const wl_comm* c);
 int wl_comm_size(const wl_comm* c);

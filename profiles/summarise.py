@@ -64,7 +64,10 @@ def finest(sub):
     return best
 
 
-lat = {"size": size, "source": f"profiles/{tag}_summary_{size}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the gfx950 note)", "kernels": {}}
+sys.path.insert(0, os.path.dirname(root))
+import bench  # noqa: E402  (kernel_config_sha: identity of the smoother kernels' sources this pass was taken on)
+
+lat = {"size": size, "kernel_config_sha": bench.kernel_config_sha(), "source": f"profiles/{tag}_summary_{size}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled per the gfx950 note)", "kernels": {}}
 for role, subs in (("A", ("k_gsrb2_A", "k_gsrb_A")), ("B", ("k_gsrb2_B", "k_gsrb_B"))):
     for sub in subs:
         k = finest(sub)

@@ -138,8 +138,11 @@ def main():
         comm.destroy()
         print(f"rank {rank}: gpu_exit ok", flush=True)
     elif mode == "gpu_rccl1":
-        # RCCL transport smoke test with the ranks one box offers (1): dlopen of librccl.so.1 shared with torch,
-        # unique-id broadcast, ncclCommInitRank, ncclAllGather on the stream, a whole slab step through the RCCL comm object.
+        # RCCL transport on the ranks one box offers (1).  Multi-rank RCCL cannot run here (RCCL refuses two ranks on one device),
+        # so this covers what one rank can: dlopen of librccl.so.1 shared with torch, the availability agreement, unique-id
+        # broadcast, ncclCommInitRank of BOTH communicators, and — through the one-rank loopback test mode (both neighbours are
+        # this rank) — the ncclSend/ncclRecv groups of the plane exchange on the compute stream and on the communicator's own
+        # stream, the in-place ncclAllGather and the device-side scalar combine.  A slab step with >1 ranks over RCCL stays unverified.
         torch.cuda.set_device(0)
         dev = torch.device("cuda", 0)
         comm = slab.RcclComm(dist, dev)
@@ -147,7 +150,7 @@ def main():
         view = wl_grid(); view.D = 3; view.nx, view.ny = 6, 5; view.gnz = view.nz = 5; view.gk = 0; view.k0, view.k1 = 1, 4
         t = torch.arange(6 * 5 * 5, dtype=torch.float32, device=dev)
         before = t.clone()
-        check(L.wl_allgather_planes(comm.handle, C.c_void_p(t.data_ptr()), C.byref(view), 1, None))
+        check(L.wl_allgather_planes(comm.handle, C.c_void_p(t.data_ptr()), C.byref(view), 1, None))     # size 1, no loopback: early return
         torch.cuda.synchronize()
         assert torch.equal(t, before)
         sim = slab.SlabSimulation(comm, (32, 32, 32), (0, 0, 0), 32, U=1, nu=0.02, ic="tgv")
@@ -155,6 +158,40 @@ def main():
         sim.mom_step_(); ref.mom_step_()
         assert np.array_equal(sim.local_field("u"), ref.field("u")) and sim.pois_n == ref.pois_n
         del sim
+        # ---- loopback: the NCCL calls themselves execute
+        check(L.wl_comm_set_loopback(comm.handle, 1))
+        g = slab.slab_grid((18, 10, 2 + 12), 0, 2, halo=2)              # a slab that is NOT the whole domain (nz < gnz)
+        ncomp = 3
+        for use_async in (0, 1):
+            for depth in (1, 2):
+                a = torch.full((ncomp, g.nz, g.ny, g.nx), -1.0, dtype=torch.float32, device=dev)    # memory order: x fastest, component slowest
+                for c in range(ncomp):
+                    for k in range(g.k0, g.k1):
+                        a[c, k] = 1000.0 * c + k
+                b = a.clone()
+                fn = L.wl_comm_halo_async if use_async else L.wl_halo_exchange
+                check(fn(comm.handle, C.c_void_p(b.data_ptr()), C.byref(g), ncomp, depth, None))
+                check(L.wl_stream_sync(None)); torch.cuda.synchronize()
+                for c in range(ncomp):
+                    for d in range(1, depth + 1):
+                        # periodic wrap onto itself: lower ghost planes = own top planes, upper ghost planes = own bottom planes
+                        assert torch.all(b[c, g.k0 - d] == 1000.0 * c + (g.k1 - d)), (use_async, depth, c, d)
+                        assert torch.all(b[c, g.k1 + d - 1] == 1000.0 * c + (g.k0 + d - 1)), (use_async, depth, c, d)
+                    if depth == 1:
+                        assert torch.all(b[c, g.k0 - 2] == -1) and torch.all(b[c, g.k1 + 1] == -1)
+                assert torch.equal(b[:, g.k0:g.k1], a[:, g.k0:g.k1])
+        t = torch.arange(6 * 5 * 5, dtype=torch.float32, device=dev)
+        check(L.wl_allgather_planes(comm.handle, C.c_void_p(t.data_ptr()), C.byref(view), 1, None))     # in-place ncclAllGather, 1 rank
+        torch.cuda.synchronize()
+        assert torch.equal(t, before)
+        rec = torch.zeros(32, dtype=torch.float32, device=dev)           # 128-byte record: 8 doubles then 8 floats
+        recd = rec[:16].view(torch.float64); recf = rec[16:24]
+        recd.copy_(torch.arange(1, 9, dtype=torch.float64)); recf.copy_(torch.arange(-3, 5, dtype=torch.float32))
+        check(L.wl_comm_combine_test(comm.handle, C.c_void_p(rec.data_ptr()), C.c_void_p(rec.data_ptr() + 64), None))
+        check(L.wl_stream_sync(None)); torch.cuda.synchronize()
+        assert torch.equal(recd.cpu(), torch.arange(1, 9, dtype=torch.float64)) and torch.equal(recf.cpu(), torch.arange(-3, 5, dtype=torch.float32))
+        st = slab.comm_stats(comm)
+        assert st["halo_exchanges"] >= 4 and st["scalar_combines"] >= 1 and st["plane_allgathers"] >= 1, st
         comm.destroy()
         print(f"rank {rank}: gpu_rccl1 ok", flush=True)
     dist.destroy_process_group()

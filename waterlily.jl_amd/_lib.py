@@ -129,6 +129,11 @@ SIGNATURES = {
     "wl_comm_rccl_unique_id": (i32, [C.c_char_p]),
     "wl_comm_rccl_create": (i32, [C.POINTER(P), i32, i32, C.c_char_p]),
     "wl_comm_callbacks_create": (i32, [C.POINTER(P), i32, i32, P, P, P]),
+    "wl_comm_rccl_available": (i32, []),
+    "wl_comm_rccl_add_async": (i32, [P, C.c_char_p]),
+    "wl_comm_set_loopback": (i32, [P, i32]),
+    "wl_comm_halo_async": (i32, [P, P, G, i32, i32, P]),
+    "wl_comm_combine_test": (i32, [P, P, P, P]),
     "wl_comm_destroy": (i32, [P]),
     "wl_comm_rank": (i32, [P]),
     "wl_comm_size": (i32, [P]),

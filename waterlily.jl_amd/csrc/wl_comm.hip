@@ -62,19 +62,32 @@ Rccl& rccl() {
     if (e__ != 0) { wl_set_error(std::string(#call) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(e__) : "rccl error")); return WL_ECOMM; } \
   } while (0)
 
+// Two communicators per rank: `comm` carries everything issued on the compute stream, `comm_async` the halo exchanges that run
+// on the communicator's own stream (wl::halo_async_begin) — a communicator is only ever used from ONE stream, so the two
+// streams' operations need no common issue order across ranks.  Until wl_comm_rccl_add_async has been called the async
+// exchanges fall back to `comm` (legal only because every rank issues the same sequence; kept for single-communicator tests).
 struct RcclComm : wl_comm {
-  ncclComm_t comm = nullptr;
+  ncclComm_t comm = nullptr, comm_async = nullptr;
   int depth = 0;
-  ~RcclComm() override { if (comm) (void)rccl().CommDestroy(comm); }
+  ~RcclComm() override { if (comm_async) (void)rccl().CommDestroy(comm_async); if (comm) (void)rccl().CommDestroy(comm); }
   int group_begin() override { if (depth++ == 0) WL_NCCL(rccl().GroupStart()); return 0; }
-  int group_end() override { if (--depth == 0) WL_NCCL(rccl().GroupEnd()); return 0; }
+  int group_end() override { if (depth > 0 && --depth == 0) WL_NCCL(rccl().GroupEnd()); return 0; }
+  int sendrecv_body(ncclComm_t cm, const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) {
+    // neighbours: lo = rank-1, hi = rank+1 (loopback: both are this rank — what it sends down comes back as its upper ghost planes and
+    // vice versa, the z-periodic wrap; sends and receives to one peer match in issue order, hence lo-send / hi-recv first)
+    const int plo = loopback ? rank : rank - 1, phi = loopback ? rank : rank + 1;
+    if (slo) WL_NCCL(rccl().Send(slo, bytes, ncclChar, plo, cm, s));
+    if (rhi) WL_NCCL(rccl().Recv(rhi, bytes, ncclChar, phi, cm, s));
+    if (shi) WL_NCCL(rccl().Send(shi, bytes, ncclChar, phi, cm, s));
+    if (rlo) WL_NCCL(rccl().Recv(rlo, bytes, ncclChar, plo, cm, s));
+    return 0;
+  }
   int sendrecv(const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) override {
     WL_TRY(group_begin());
-    if (slo) WL_NCCL(rccl().Send(slo, bytes, ncclChar, rank - 1, comm, s));
-    if (rlo) WL_NCCL(rccl().Recv(rlo, bytes, ncclChar, rank - 1, comm, s));
-    if (shi) WL_NCCL(rccl().Send(shi, bytes, ncclChar, rank + 1, comm, s));
-    if (rhi) WL_NCCL(rccl().Recv(rhi, bytes, ncclChar, rank + 1, comm, s));
-    return group_end();
+    ncclComm_t cm = (comm_async && s == cs && cs) ? comm_async : comm;
+    const int rc = sendrecv_body(cm, slo, rlo, shi, rhi, bytes, s);
+    const int re = group_end();            // always closes the group opened above, also on the error path
+    return rc ? rc : re;
   }
   int allgather(const void* send, void* recv, size_t bytes_each, hipStream_t s) override {
     WL_NCCL(rccl().AllGather(send, recv, bytes_each, ncclChar, comm, s));
@@ -105,8 +118,8 @@ __global__ void k_combine(const char* __restrict__ gathered, int nranks, double*
 
 namespace wl {
 int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s) {
-  if (!c || c->size == 1 || g.D != 3 || g.nz == g.gnz) return 0;   // single domain / replicated level: nothing to exchange
-  const bool has_lo = (g.gk + g.k0 > 1), has_hi = (g.gk + g.k1 < g.gnz - 1);
+  if (!c || (c->size == 1 && !c->loopback) || g.D != 3 || g.nz == g.gnz) return 0;   // single domain / replicated level: nothing to exchange
+  const bool has_lo = c->loopback || (g.gk + g.k0 > 1), has_hi = c->loopback || (g.gk + g.k1 < g.gnz - 1);
   const size_t bytes = (size_t)depth * (size_t)g.sz * sizeof(float);
   if (g.k1 - g.k0 < depth || g.k0 < depth) { wl_set_error("halo deeper than the slab"); return WL_EINVAL; }
   c->n_halo++; c->halo_bytes += (long)bytes * ncomp * ((has_lo ? 1 : 0) + (has_hi ? 1 : 0));
@@ -120,7 +133,7 @@ int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t
   return c->group_end();
 }
 int halo_async_begin(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t compute) {
-  if (!c || c->size == 1 || g.D != 3 || g.nz == g.gnz) return 0;
+  if (!c || (c->size == 1 && !c->loopback) || g.D != 3 || g.nz == g.gnz) return 0;
   WL_TRY(c->ensure_async());
   WL_HIP(hipEventRecord(c->ev_ready, compute));
   WL_HIP(hipStreamWaitEvent(c->cs, c->ev_ready, 0));
@@ -129,12 +142,12 @@ int halo_async_begin(wl_comm* c, float* a, const GridX& g, int ncomp, int depth,
   return 0;
 }
 int halo_async_wait(wl_comm* c, hipStream_t compute) {
-  if (!c || c->size == 1 || !c->cs) return 0;
+  if (!c || (c->size == 1 && !c->loopback) || !c->cs) return 0;
   WL_HIP(hipStreamWaitEvent(compute, c->ev_done, 0));
   return 0;
 }
 int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s) {
-  if (!c || c->size == 1) return 0;
+  if (!c || (c->size == 1 && !c->loopback)) return 0;
   WL_TRY(c->ensure_scratch());
   c->n_combine++;
   // res_d (64 B) and res_f (32 B at +64) are adjacent: one 128-byte record per rank
@@ -143,7 +156,7 @@ int combine_results(wl_comm* c, const RedWs& ws, hipStream_t s) {
   WL_LAUNCH_CHECK(); return 0;
 }
 int allgather_planes(wl_comm* c, float* a, const GridX& view, int ncomp, hipStream_t s) {
-  if (!c || c->size == 1) return 0;
+  if (!c || (c->size == 1 && !c->loopback)) return 0;
   const size_t block = (size_t)(view.k1 - view.k0) * (size_t)view.sz;       // floats per rank
   c->n_gather += ncomp;
   for (int q = 0; q < ncomp; q++) {
@@ -170,6 +183,27 @@ int wl_comm_rccl_create(wl_comm** out, int rank, int size, const char uid[128]) 
   ncclResult_t e = r.CommInitRank(&c->comm, size, id, rank);
   if (e != 0) { wl_set_error(std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(e) : "error")); delete c; return WL_ECOMM; }
   *out = c; return 0;
+}
+int wl_comm_rccl_available(void) { return rccl().ok ? 1 : 0; }
+int wl_comm_rccl_add_async(wl_comm* cc, const char uid[128]) {
+  RcclComm* c = dynamic_cast<RcclComm*>(cc);
+  WL_CHECK(c && !c->comm_async, "not an RCCL communicator (or it already has its async communicator)");
+  ncclUniqueId id; memcpy(id.internal, uid, 128);
+  ncclResult_t e = rccl().CommInitRank(&c->comm_async, c->size, id, c->rank);
+  if (e != 0) { c->comm_async = nullptr; wl_set_error(std::string("ncclCommInitRank (async): ") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "error")); return WL_ECOMM; }
+  return 0;
+}
+int wl_comm_set_loopback(wl_comm* c, int on) { WL_CHECK(c && c->size == 1, "loopback is a one-rank test mode"); c->loopback = on != 0; return 0; }
+int wl_comm_halo_async(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* st) {
+  WL_CHECK(g && g->D == 3, "halo exchange needs a 3-D slab grid");
+  WL_TRY(wl::halo_async_begin(c, a, gx(*g), ncomp, depth, wl_stream(st)));
+  return wl::halo_async_wait(c, wl_stream(st));
+}
+int wl_comm_combine_test(wl_comm* c, double* d8, float* f8, void* st) {
+  // test hook: Σ over ranks of d8[0..7], max over ranks of f8[0..7] through the production combine path (device pointers, adjacent 64+32 B)
+  WL_CHECK(c && d8 && (char*)f8 == (char*)d8 + 64, "d8/f8 must be one 128-byte record");
+  RedWs ws{}; ws.res_d = d8; ws.res_f = f8;
+  return wl::combine_results(c, ws, wl_stream(st));
 }
 int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_sendrecv_fn sr, wl_allgather_fn ag) {
   WL_CHECK(out && sr && ag && size >= 1 && rank >= 0 && rank < size, "bad arguments");

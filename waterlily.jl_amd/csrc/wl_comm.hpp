@@ -4,6 +4,7 @@
 
 struct wl_comm {
   int rank = 0, size = 1;
+  bool loopback = false;    // one-rank TEST mode: both neighbours are this rank (exercises the transport calls that size==1 skips)
   void* gather = nullptr;   // device scratch for scalar all-gathers: size * 128 bytes
   virtual ~wl_comm();
   // lo neighbour = rank-1, hi neighbour = rank+1; pointers are NULL where there is no neighbour

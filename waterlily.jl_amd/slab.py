@@ -101,27 +101,52 @@ class CallbackComm:
 
 
 class RcclComm:
-    """wl_comm over RCCL: the unique id is created on rank 0 and broadcast through torch.distributed."""
+    """wl_comm over RCCL.  Two communicators (compute-stream traffic / overlapped halo stream), whose unique ids are created on
+    rank 0 and broadcast through torch.distributed.  Ranks first AGREE (all-reduce) that RCCL is loadable everywhere, so that
+    no rank enters ncclCommInitRank while another has already given up; any failure raises on every rank — there is no fallback."""
 
-    def __init__(self, dist, device):
+    def __init__(self, dist, device, dual=True):
         import torch
         self.rank, self.size = dist.get_rank(), dist.get_world_size()
-        uid = C.create_string_buffer(128)
+        L = lib()
+        on_dev = dist.get_backend() == "nccl"
+        ok = torch.tensor([int(L.wl_comm_rccl_available())], dtype=torch.int32, device=device if on_dev else "cpu")
+        if self.size > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            raise WlCommError("RCCL (librccl.so.1) is not loadable on every rank")
+        nid = 2 if dual else 1
+        raw = bytearray(128 * nid + 1)
         if self.rank == 0:
-            check(lib().wl_comm_rccl_unique_id(uid))
-        t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).clone()
-        if dist.get_backend() == "nccl":
-            t = t.to(device)
-        dist.broadcast(t, 0)
+            good = 1
+            for q in range(nid):
+                uid = C.create_string_buffer(128)
+                if L.wl_comm_rccl_unique_id(uid) != 0:
+                    good = 0
+                raw[128 * q:128 * (q + 1)] = uid.raw
+            raw[-1] = good
+        t = torch.frombuffer(raw, dtype=torch.uint8).clone()
+        if self.size > 1:
+            if on_dev:
+                t = t.to(device)
+            dist.broadcast(t, 0)
         raw = bytes(t.cpu().numpy().tobytes())
+        if raw[-1] != 1:
+            raise WlCommError("ncclGetUniqueId failed on rank 0")
         h = C.c_void_p()
-        check(lib().wl_comm_rccl_create(C.byref(h), self.rank, self.size, raw))
+        check(L.wl_comm_rccl_create(C.byref(h), self.rank, self.size, raw[:128]))
         self.handle = h
+        if dual:
+            check(L.wl_comm_rccl_add_async(h, raw[128:256]))
 
     def destroy(self):
         if self.handle:
             lib().wl_comm_destroy(self.handle)
             self.handle = None
+
+
+class WlCommError(RuntimeError):
+    pass
 
 
 class SlabSimulation:
@@ -238,28 +263,16 @@ def comm_stats(comm):
     return {"halo_exchanges": int(out[0]), "halo_bytes_sent": int(out[1]), "scalar_combines": int(out[2]), "plane_allgathers": int(out[3])}
 
 
-def make_comm(dist, device, prefer="rccl"):
-    """RCCL transport when the process group is nccl(=RCCL); if creating it fails on ANY rank, every rank falls back
-    (decided by an all-reduce, so nobody is left waiting) to the host-staged callback transport over a gloo group."""
-    import torch
-    if prefer == "rccl" and dist.get_backend() == "nccl":
-        comm, ok = None, 1
-        try:
-            comm = RcclComm(dist, device)
-        except Exception as e:   # noqa: BLE001
-            print(f"[rank {dist.get_rank()}] RCCL transport unavailable ({e!r}); falling back to host staging", flush=True)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            return comm
-        if comm is not None:
-            comm.destroy()
-        return CallbackComm(dist, group=dist.new_group(backend="gloo"))
+def make_comm(dist, device):
+    """The transport follows the process group: nccl(=RCCL) -> RcclComm (ncclSend/Recv over xGMI), and a failure to create it is an
+    error on every rank (no silent fallback: a scaling number on host staging would be meaningless); gloo -> the host-staged
+    callback transport, which exists for tests and one-GPU rehearsals and is labelled as such in the bench line."""
+    if dist.get_backend() == "nccl":
+        return RcclComm(dist, device)
     return CallbackComm(dist)
 
 
-def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=None):
+def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=None, cpu_baseline=None):
     """bench.py --gpus N (N>1): the same 512³ TGV cut into N z-slabs (strong scaling), one process per GPU."""
     import torch
     import torch.distributed as dist
@@ -310,6 +323,11 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
                           "dt_last": float(sim.dt[-1]),
                           "comm_per_step_rank0": {k: (cs1[k] - cs0[k]) / args.steps for k in cs1}},
                "roofline": roof, "cpu_baseline": None}
+        if cpu_baseline is not None:      # outside the timed region; the other ranks wait at the barrier below
+            try:
+                out["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     dist.barrier()
     del sim
