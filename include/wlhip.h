@@ -177,7 +177,9 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    "jacobi_march"[1] z-marching constant-coefficient Jacobi  "farmask"[1], "hybrid"[1] BDIM! fast paths away from a body
    "zsplit"[1] pair smoother on the planes away from a body (levels >= 16 M cells; 2: any size, v >= 4: >= v·2^20 cells)
    "defer_shift"[1] residual!'s mean shift + solver!'s first norms folded into the finest level's z-marching Jacobi!
-   "skip_fill"[1] Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi! */
+   "skip_fill"[1] Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi!
+   "convt"[1] LDS-tiled z-marching conv_diff!+BDIM! (NoBody, no periodic direction, f not stored; v > 1: on with z-chunks of v planes)
+   "convt_min"[8192] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0) */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
    g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).

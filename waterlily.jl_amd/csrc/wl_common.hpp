@@ -209,6 +209,11 @@ int bc_vec_fn(float* a, const float* Ub, const GridX& g, int saveexit, unsigned 
 int add_field(float* r, const float* gfield, size_t n, hipStream_t s);
 int meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const GridX& g, float e, hipStream_t s);
 int meanflow_uu(float* tau, const float* UU, const float* U, const GridX& g, hipStream_t s);
+// z-marching LDS-tiled conv_diff!+BDIM! (wl_convt.hip): the default fused path on grids that fill the chip
+void conv_tile_enable(int on, int chunk);
+void conv_tile_min(long tile_planes);
+bool conv_tile_ok(const GridX& g, unsigned per, int nplanes);
+int conv_tile(const float* u_adv, const GridX& g, float nu, int scheme, int ka, int kb, const void* bdim_args, hipStream_t s);
 void conv_march_enable(int on);
 void jacobi_march_enable(int on);
 bool conv_march_ok(const GridX& g);

@@ -661,11 +661,15 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   const bool small = g.cs < (1L << 30);   // 32-bit element offsets inside one component
   BdimArgs b0{nullptr, nullptr, nullptr, 0.f, 0.f, 1.f, 0, 0, {0.f, 0.f, 0.f}};
   const BdimArgs ba = bd ? *bd : b0;
-  const bool march = D == 3 && wl::conv_march_ok(g);   // z-marching variant (wl_convm.hip): same arithmetic, the z-star in registers
+  // fused NoBody conv_diff!+BDIM! without the f store: the LDS-tiled z-marching kernel (wl_convt.hip) on the owned interior planes
+  const int own_a = kfirst > g.k0 ? kfirst : g.k0, own_b = klast < g.k1 ? klast : g.k1;
+  const bool tiled = D == 3 && bd && !bd->near && !r && bd->cl_on && wl::conv_tile_ok(g, per, own_b - own_a);
+  if (tiled) WL_TRY(wl::conv_tile(u, g, nu, SCH, own_a, own_b, bd, s));
+  const bool march = !tiled && D == 3 && wl::conv_march_ok(g);   // z-marching variant (wl_convm.hip): same arithmetic, the z-star in registers
   if (march && !(bd && bd->near)) WL_TRY(wl::conv_march(r, u, g, nu, per, SCH, kfirst, klast, bd, s));
 #define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \
   hipLaunchKernelGGL((k_conv_diff<D, SCH, PERF, IDXT, FUSEF>), grid, dim3(WL_BLOCK), 0, s, g, r, u, nu, per, kfirst, ba)
-  if (march && !(bd && bd->near)) {}
+  if (tiled || (march && !(bd && bd->near))) {}
   else if (bd && bd->near) { if (per) { if (small) WL_CD(1, int, 2); else WL_CD(1, long, 2); } else { if (small) WL_CD(0, int, 2); else WL_CD(0, long, 2); } }
   else if (bd) { if (per) { if (small) WL_CD(1, int, 1); else WL_CD(1, long, 1); } else { if (small) WL_CD(0, int, 1); else WL_CD(0, long, 1); } }
   else    { if (per) { if (small) WL_CD(1, int, 0); else WL_CD(1, long, 0); } else { if (small) WL_CD(0, int, 0); else WL_CD(0, long, 0); } }

@@ -604,6 +604,8 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "jacobi_march") { wl::jacobi_march_enable(value); return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
+  if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
