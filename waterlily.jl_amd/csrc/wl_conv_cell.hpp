@@ -12,6 +12,13 @@ __device__ __forceinline__ float median3(float a, float b, float c) { return __b
 // quotient of a float by 6 is never closer than ~2^-27 (relative) to a rounding midpoint, far above the 2^-53 product error.
 #ifdef WL_NO_DIV6
 __device__ __forceinline__ float div6(float x) { return x / 6; }
+#elif defined(WL_DIV6_FMA)
+// EXPERIMENT (not the default): q = x·RN(1/6), r = x − 6q (exact, one FMA), q + r·RN(1/6) (one FMA) — three full-rate
+// instructions.  Verified exhaustively against IEEE x/6.0f over all 2^32 bit patterns (tools/check_div6_fma.c): correctly
+// rounded for every |x| ≥ 2^-125; below that the quotient is subnormal, exact ties exist and 2.8 M inputs round the other
+// way (and −0 gives +0).  A guard branch costs more than it saves (it splits the flux code into many basic blocks: 150+
+// spilled VGPRs), so the default stays the double-precision product below, exact for every float.
+__device__ __forceinline__ float div6(float x) { const float c = 0x1.555556p-3f; const float q = x * c; const float r = __builtin_fmaf(-6.f, q, x); return __builtin_fmaf(r, c, q); }
 #else
 __device__ __forceinline__ float div6(float x) { return (float)((double)x * (1.0 / 6.0)); }
 #endif

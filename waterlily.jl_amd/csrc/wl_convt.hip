@@ -16,6 +16,7 @@
 // r += Φ(I) then r −= Φ(I+δ)) ⇒ bit-identical results.  Scope: D = 3, no periodic direction, BDIM! fused (NoBody), f not
 // stored; everything else stays on k_conv_diff.
 #include <cstdlib>
+#include <type_traits>
 
 #include "wl_conv_cell.hpp"
 
@@ -60,12 +61,18 @@ __device__ __forceinline__ float2 pair_fix(float2 t, int mode) { return make_flo
 // wl: F is the first interior cell (Julia index 2: the reference's ϕuL form), wu: F is the upper ghost (index N: ϕuR).
 // Same statements as face_flux()/cd_cell (wl_conv_cell.hpp) for the lower (a,b,c,d = f[I−2δ],f[I−δ],f[I],f[I+δ]) and the upper
 // (f[I−δ],f[I],f[I+δ],f[I+2δ]) face of a cell.   src/Flow.jl:8-11,47-57
-template <int SCH>
+// WALLS = 0: the caller knows that neither flag can be set (tile away from the x/y walls, plane away from the z walls).
+template <int SCH, int WALLS>
 __device__ __forceinline__ float ct_flux(float U, float a, float b, float c, float d, bool wl, bool wu, float nu) {
+#ifdef WL_CT_CHEAPFLUX   // timing experiment only (wrong results): what the kernel costs without the limiter arithmetic
+  return U * (a + d) - nu * (c - b);
+#endif
   const bool pos = U > 0;
   float X = lam<SCH>(pos ? a : d, pos ? b : c, pos ? c : b);
-  const bool use_avg = (wl && pos) || (wu && (U < 0));
-  X = use_avg ? (c + b) / 2 : X;
+  if (WALLS) {
+    const bool use_avg = (wl && pos) || (wu && (U < 0));
+    X = use_avg ? (c + b) / 2 : X;
+  }
   return U * X - nu * (c - b);
 }
 
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
   float zf[3][2];     // Φ at the lower z-face of the pair, per component (carried from the previous plane)
 
   // Φ at the face k+1 (upper z-face of plane k = lower z-face of plane k+1) for the three components of the pair;  U = (u_z[F] + u_z[F−δa])/2 on plane k+1
-  auto zfaces = [&](int k, const float2* Zm1, const float2* C1, const float2* Zp1, const float2* Zp2, const float* Pp, float (*Pz)[2]) {
+  auto zfaces = [&](auto wtag, int k, const float2* Zm1, const float2* C1, const float2* Zp1, const float2* Zp2, const float* Pp, float (*Pz)[2]) {
     const int Kg = g.gk + k;
     const bool wlz = (Kg + 1 == 1), wuz = (Kg + 1 == g.gnz - 1);
     const float2 Exz = lds2(Pp + 2 * CT_P - 2);      // u_z(x−2.., y, k+1): .y = u_z(x−1)
@@ -153,7 +160,7 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
         if (a == 0) Uz = (sel(Zp1[2], e) + (e ? Zp1[2].x : Exz.y)) / 2;
         else if (a == 1) Uz = (sel(Zp1[2], e) + sel(Eyz, e)) / 2;
         else Uz = (sel(Zp1[2], e) + sel(C1[2], e)) / 2;
-        Pz[a][e] = ct_flux<SCH>(Uz, sel(Zm1[a], e), sel(C1[a], e), sel(Zp1[a], e), sel(Zp2[a], e), wlz, wuz, nu);
+        Pz[a][e] = ct_flux<SCH, decltype(wtag)::value>(Uz, sel(Zm1[a], e), sel(C1[a], e), sel(Zp1[a], e), sel(Zp2[a], e), wlz, wuz, nu);
       }
     }
   };
@@ -170,10 +177,15 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
     const float* Pp = lds + ((k + 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) { C1[cc] = lds2(P0 + cc * CT_P); Zm1[cc] = lds2(Pm + cc * CT_P); Zp1[cc] = lds2(Pp + cc * CT_P); }
-    zfaces(k, Zm1, C1, Zp1, Zp2, Pp, zf);
+    zfaces(std::integral_constant<int, 1>{}, k, Zm1, C1, Zp1, Zp2, Pp, zf);
     __syncthreads();
   }
   const int N[3] = {g.nx, g.ny, g.gnz};
+#ifdef WL_CT_NOWALLSPLIT
+  const bool tile_walls = true;    // experiment: every tile runs the loop with the wall forms
+#else
+  const bool tile_walls = tx == 0 || tx == ntx - 1 || ty == 0 || ty == nty - 1;
+#endif
   // The results of plane k are stored at the top of iteration k+1, AFTER that iteration's loads have been issued: every wait on
   // the vector-memory counter (in order, loads and stores alike) then only ever covers operations issued a whole plane earlier.
   float2 un[3];
@@ -187,97 +199,104 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
       else { const unsigned o0 = (unsigned)a * cs + kqo + (unsigned)x + (unsigned)y * sy; if (in0) bd.uout[o0] = un[a].x; if (in1) bd.uout[o0 + 1] = un[a].y; }
     }
   };
-  for (int k = ks; k < ke; k++) {
-    // ---- stage: plane k+2 (loaded during the previous iteration) → LDS; its centres are this plane's f[I+2δz]; issue plane k+3
-    float2 Zp2[3];
+  // The main loop exists twice: WALLS = 1 for tiles that touch an x or y wall (the reference's ϕuL/ϕuR forms are live on some of
+  // their faces), WALLS = 0 for the others (≈70 % of the tiles at 512²) without the wall forms.  Two separate loops, not a branch
+  // inside one loop: each is straight-line code for the register allocator.  The z faces keep their run-time wall flags.
+  auto mainloop = [&](auto wtag) {
+    constexpr int WALLS = decltype(wtag)::value;
+    for (int k = ks; k < ke; k++) {
+      // ---- stage: plane k+2 (loaded during the previous iteration) → LDS; its centres are this plane's f[I+2δz]; issue plane k+3
+      float2 Zp2[3];
 #pragma unroll
-    for (int cc = 0; cc < 3; cc++) Zp2[cc] = FULL ? S.c[cc] : pair_fix(S.c[cc], pc.mode);
-    write_plane(k + 2, S);
-    S = load_plane(k + 3);
-    const unsigned ko = (unsigned)k * sz;
-    float2 u0v[3];
-    if (!U0ADV) {
+      for (int cc = 0; cc < 3; cc++) Zp2[cc] = FULL ? S.c[cc] : pair_fix(S.c[cc], pc.mode);
+      write_plane(k + 2, S);
+      S = load_plane(k + 3);
+      const unsigned ko = (unsigned)k * sz;
+      float2 u0v[3];
+      if (!U0ADV) {
 #pragma unroll
-      for (int a = 0; a < 3; a++) { u0v[a] = ldg2(bd.u0, (unsigned)a * cs + ko + pc.off); if (!FULL) u0v[a] = pair_fix(u0v[a], pc.mode); }
-    }
-    if (k > ks) store_plane(k - 1);
-    const float* Pm = lds + ((k - 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
-    const float* P0 = lds + (k & (CT_NSLOT - 1)) * CT_SLOT + my;
-    const float* Pp = lds + ((k + 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
-    float2 C1[3], Zm1[3], Zp1[3];
-#pragma unroll
-    for (int cc = 0; cc < 3; cc++) { C1[cc] = lds2(P0 + cc * CT_P); Zm1[cc] = lds2(Pm + cc * CT_P); Zp1[cc] = lds2(Pp + cc * CT_P); }
-    float acc[3][2];
-    {
-      float2 CA[3], CC[3], Ym2[3], Ym1[3], Yp1[3], Yp2[3];
-#pragma unroll
-      for (int cc = 0; cc < 3; cc++) {
-        CA[cc] = lds2(P0 + cc * CT_P - 2); CC[cc] = lds2(P0 + cc * CT_P + 2);
-        Ym2[cc] = lds2(P0 + cc * CT_P - 2 * CT_W); Ym1[cc] = lds2(P0 + cc * CT_P - CT_W);
-        Yp1[cc] = lds2(P0 + cc * CT_P + CT_W); Yp2[cc] = lds2(P0 + cc * CT_P + 2 * CT_W);
+        for (int a = 0; a < 3; a++) { u0v[a] = ldg2(bd.u0, (unsigned)a * cs + ko + pc.off); if (!FULL) u0v[a] = pair_fix(u0v[a], pc.mode); }
       }
-      const float Exy = lds2(P0 + 1 * CT_P + CT_W - 2).y;      // u_y(x−1, y+1, k)
-      const float Eyx = lds2(P0 + 0 * CT_P - CT_W + 2).x;      // u_x(x+2, y−1, k)
-      const float Ezx = lds2(Pm + 0 * CT_P + 2).x;             // u_x(x+2, y, k−1)
-      const float2 Ezy = lds2(Pm + 1 * CT_P + CT_W);           // u_y(x.., y+1, k−1)
-      // rows of u_x and u_y along x: index j ↔ cell x−2+j
-      const float rx[6] = {CA[0].x, CA[0].y, C1[0].x, C1[0].y, CC[0].x, CC[0].y};
-      const float ry[6] = {CA[1].x, CA[1].y, C1[1].x, C1[1].y, CC[1].x, CC[1].y};
+      if (k > ks) store_plane(k - 1);
+      const float* Pm = lds + ((k - 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
+      const float* P0 = lds + (k & (CT_NSLOT - 1)) * CT_SLOT + my;
+      const float* Pp = lds + ((k + 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
+      float2 C1[3], Zm1[3], Zp1[3];
+#pragma unroll
+      for (int cc = 0; cc < 3; cc++) { C1[cc] = lds2(P0 + cc * CT_P); Zm1[cc] = lds2(Pm + cc * CT_P); Zp1[cc] = lds2(Pp + cc * CT_P); }
+      float acc[3][2];
+      {
+        float2 CA[3], CC[3], Ym2[3], Ym1[3], Yp1[3], Yp2[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+          CA[cc] = lds2(P0 + cc * CT_P - 2); CC[cc] = lds2(P0 + cc * CT_P + 2);
+          Ym2[cc] = lds2(P0 + cc * CT_P - 2 * CT_W); Ym1[cc] = lds2(P0 + cc * CT_P - CT_W);
+          Yp1[cc] = lds2(P0 + cc * CT_P + CT_W); Yp2[cc] = lds2(P0 + cc * CT_P + 2 * CT_W);
+        }
+        const float Exy = lds2(P0 + 1 * CT_P + CT_W - 2).y;      // u_y(x−1, y+1, k)
+        const float Eyx = lds2(P0 + 0 * CT_P - CT_W + 2).x;      // u_x(x+2, y−1, k)
+        const float Ezx = lds2(Pm + 0 * CT_P + 2).x;             // u_x(x+2, y, k−1)
+        const float2 Ezy = lds2(Pm + 1 * CT_P + CT_W);           // u_y(x.., y+1, k−1)
+        // rows of u_x and u_y along x: index j ↔ cell x−2+j
+        const float rx[6] = {CA[0].x, CA[0].y, C1[0].x, C1[0].y, CC[0].x, CC[0].y};
+        const float ry[6] = {CA[1].x, CA[1].y, C1[1].x, C1[1].y, CC[1].x, CC[1].y};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+          const float r[6] = {CA[a].x, CA[a].y, C1[a].x, C1[a].y, CC[a].x, CC[a].y};
+          // ---- b = x: faces x, x+1, x+2;  U = (u_x[F] + u_x[F−δa])/2                                    src/Flow.jl:3,47
+          float Ux[3];
+          if (a == 0) { Ux[0] = (rx[2] + rx[1]) / 2; Ux[1] = (rx[3] + rx[2]) / 2; Ux[2] = (rx[4] + rx[3]) / 2; }
+          else if (a == 1) { Ux[0] = (rx[2] + Ym1[0].x) / 2; Ux[1] = (rx[3] + Ym1[0].y) / 2; Ux[2] = (rx[4] + Eyx) / 2; }
+          else { Ux[0] = (rx[2] + Zm1[0].x) / 2; Ux[1] = (rx[3] + Zm1[0].y) / 2; Ux[2] = (rx[4] + Ezx) / 2; }
+          const float Px0 = ct_flux<SCH, WALLS>(Ux[0], r[0], r[1], r[2], r[3], wlx, wux0, nu);
+          const float Px1 = ct_flux<SCH, WALLS>(Ux[1], r[1], r[2], r[3], r[4], false, wux1, nu);
+          const float Px2 = ct_flux<SCH, WALLS>(Ux[2], r[2], r[3], r[4], r[5], false, wux2, nu);
+          float a0 = 0.f, a1 = 0.f;
+          a0 = a0 + Px0; a0 = a0 - Px1;
+          a1 = a1 + Px1; a1 = a1 - Px2;
+          // ---- b = y: lower face (row y) and upper face (row y+1) of each cell;  U = (u_y[F] + u_y[F−δa])/2
+#pragma unroll
+          for (int e = 0; e < 2; e++) {
+            const float vm2 = sel(Ym2[a], e), vm1 = sel(Ym1[a], e), v0 = sel(C1[a], e), vp1 = sel(Yp1[a], e), vp2 = sel(Yp2[a], e);
+            float Ul, Uu;
+            if (a == 0) { Ul = (ry[2 + e] + ry[1 + e]) / 2; Uu = (sel(Yp1[1], e) + (e ? Yp1[1].x : Exy)) / 2; }
+            else if (a == 1) { Ul = (v0 + vm1) / 2; Uu = (vp1 + v0) / 2; }
+            else { Ul = (sel(C1[1], e) + sel(Zm1[1], e)) / 2; Uu = (sel(Yp1[1], e) + sel(Ezy, e)) / 2; }
+            const float Pl = ct_flux<SCH, WALLS>(Ul, vm2, vm1, v0, vp1, wly, wuy0, nu);
+            const float Pu = ct_flux<SCH, WALLS>(Uu, vm1, v0, vp1, vp2, false, wuy1, nu);
+            if (e == 0) { a0 = a0 + Pl; a0 = a0 - Pu; } else { a1 = a1 + Pl; a1 = a1 - Pu; }
+          }
+          acc[a][0] = a0; acc[a][1] = a1;
+        }
+      }
+      // ---- b = z: lower face carried from the previous plane, upper face k+1 evaluated now
+      float Pz[3][2];
+      zfaces(std::integral_constant<int, 1>{}, k, Zm1, C1, Zp1, Zp2, Pp, Pz);
 #pragma unroll
       for (int a = 0; a < 3; a++) {
-        const float r[6] = {CA[a].x, CA[a].y, C1[a].x, C1[a].y, CC[a].x, CC[a].y};
-        // ---- b = x: faces x, x+1, x+2;  U = (u_x[F] + u_x[F−δa])/2                                    src/Flow.jl:3,47
-        float Ux[3];
-        if (a == 0) { Ux[0] = (rx[2] + rx[1]) / 2; Ux[1] = (rx[3] + rx[2]) / 2; Ux[2] = (rx[4] + rx[3]) / 2; }
-        else if (a == 1) { Ux[0] = (rx[2] + Ym1[0].x) / 2; Ux[1] = (rx[3] + Ym1[0].y) / 2; Ux[2] = (rx[4] + Eyx) / 2; }
-        else { Ux[0] = (rx[2] + Zm1[0].x) / 2; Ux[1] = (rx[3] + Zm1[0].y) / 2; Ux[2] = (rx[4] + Ezx) / 2; }
-        const float Px0 = ct_flux<SCH>(Ux[0], r[0], r[1], r[2], r[3], wlx, wux0, nu);
-        const float Px1 = ct_flux<SCH>(Ux[1], r[1], r[2], r[3], r[4], false, wux1, nu);
-        const float Px2 = ct_flux<SCH>(Ux[2], r[2], r[3], r[4], r[5], false, wux2, nu);
-        float a0 = 0.f, a1 = 0.f;
-        a0 = a0 + Px0; a0 = a0 - Px1;
-        a1 = a1 + Px1; a1 = a1 - Px2;
-        // ---- b = y: lower face (row y) and upper face (row y+1) of each cell;  U = (u_y[F] + u_y[F−δa])/2
+#pragma unroll
+        for (int e = 0; e < 2; e++) { float t = acc[a][e]; t = t + zf[a][e]; t = t - Pz[a][e]; acc[a][e] = t; zf[a][e] = Pz[a][e]; }
+      }
+      // ---- BDIM! (NoBody: μ₁ ≡ 0, V ≡ 0) with scale_u! folded: f = u⁰ + Δt·r ; u_out = (u·pre + μ₀·f)·post       src/Flow.jl:176-180
+      const int Kg = g.gk + k;
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const float2 u0a = U0ADV ? C1[a] : u0v[a];
+        const int I0[3] = {x + 1, y + 1, Kg + 1}, I1[3] = {x + 2, y + 1, Kg + 1};      // Julia indices of the two cells
+        const float m00 = wl::wl_cl_coef(I0[a], N[a], bd.cl_c[a]), m01 = wl::wl_cl_coef(I1[a], N[a], bd.cl_c[a]);   // μ₀ of a verified NoBody field
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          const float vm2 = sel(Ym2[a], e), vm1 = sel(Ym1[a], e), v0 = sel(C1[a], e), vp1 = sel(Yp1[a], e), vp2 = sel(Yp2[a], e);
-          float Ul, Uu;
-          if (a == 0) { Ul = (ry[2 + e] + ry[1 + e]) / 2; Uu = (sel(Yp1[1], e) + (e ? Yp1[1].x : Exy)) / 2; }
-          else if (a == 1) { Ul = (v0 + vm1) / 2; Uu = (vp1 + v0) / 2; }
-          else { Ul = (sel(C1[1], e) + sel(Zm1[1], e)) / 2; Uu = (sel(Yp1[1], e) + sel(Ezy, e)) / 2; }
-          const float Pl = ct_flux<SCH>(Ul, vm2, vm1, v0, vp1, wly, wuy0, nu);
-          const float Pu = ct_flux<SCH>(Uu, vm1, v0, vp1, vp2, false, wuy1, nu);
-          if (e == 0) { a0 = a0 + Pl; a0 = a0 - Pu; } else { a1 = a1 + Pl; a1 = a1 - Pu; }
+          const float fn = sel(u0a, e) + bd.dt * acc[a][e] - 0.f;
+          const float xx = (0.f / 2 + 0.f) + (e ? m01 : m00) * fn;
+          float v = (bd.pre == 0.f) ? xx : (sel(C1[a], e) * bd.pre + xx);
+          if (bd.scale_after) v = v * bd.post;
+          if (e) un[a].y = v; else un[a].x = v;
         }
-        acc[a][0] = a0; acc[a][1] = a1;
       }
+      __syncthreads();     // plane k+2 is visible to the next iteration; nobody still reads the slot the next iteration overwrites
     }
-    // ---- b = z: lower face carried from the previous plane, upper face k+1 evaluated now
-    float Pz[3][2];
-    zfaces(k, Zm1, C1, Zp1, Zp2, Pp, Pz);
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-#pragma unroll
-      for (int e = 0; e < 2; e++) { float t = acc[a][e]; t = t + zf[a][e]; t = t - Pz[a][e]; acc[a][e] = t; zf[a][e] = Pz[a][e]; }
-    }
-    // ---- BDIM! (NoBody: μ₁ ≡ 0, V ≡ 0) with scale_u! folded: f = u⁰ + Δt·r ; u_out = (u·pre + μ₀·f)·post       src/Flow.jl:176-180
-    const int Kg = g.gk + k;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-      const float2 u0a = U0ADV ? C1[a] : u0v[a];
-      const int I0[3] = {x + 1, y + 1, Kg + 1}, I1[3] = {x + 2, y + 1, Kg + 1};      // Julia indices of the two cells
-      const float m00 = wl::wl_cl_coef(I0[a], N[a], bd.cl_c[a]), m01 = wl::wl_cl_coef(I1[a], N[a], bd.cl_c[a]);   // μ₀ of a verified NoBody field
-#pragma unroll
-      for (int e = 0; e < 2; e++) {
-        const float fn = sel(u0a, e) + bd.dt * acc[a][e] - 0.f;
-        const float xx = (0.f / 2 + 0.f) + (e ? m01 : m00) * fn;
-        float v = (bd.pre == 0.f) ? xx : (sel(C1[a], e) * bd.pre + xx);
-        if (bd.scale_after) v = v * bd.post;
-        if (e) un[a].y = v; else un[a].x = v;
-      }
-    }
-    __syncthreads();     // plane k+2 is visible to the next iteration; nobody still reads the slot the next iteration overwrites
-  }
+  };
+  if (tile_walls) mainloop(std::integral_constant<int, 1>{}); else mainloop(std::integral_constant<int, 0>{});
   store_plane(ke - 1);
 }
 }  // namespace
