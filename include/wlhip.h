@@ -161,10 +161,17 @@ typedef struct wl_sim_desc {
   int32_t has_body;         /* 0: NoBody fast path (μ₁≡0, V≡0 never read) */
   /* caller-owned flow arrays (NULL => the handle allocates and owns them) */
   float *u, *u0, *f, *p, *sigma, *V, *mu0, *mu1;
+  /* optional caller-owned SPARE velocity array (same size as u).  The fused kernels are out of place (conv_diff!+BDIM! and the
+     projection tail write a velocity array other than the one they read) and `u⁰ .= u` (src/Flow.jl:157) is a pointer swap, so
+     the handle PERMUTES the roles of the three arrays {u, u0, us} from step to step.  With caller-owned u and u0:
+       us given : full-speed path; after every wl_sim_mom_step read the current roles back with wl_sim_field(s,"u"|"u0"|"us")
+                  (the Julia binding re-points its HipArray objects; the three buffers stay the caller's to free);
+       us NULL  : pointers never move — `u⁰ .= u` is a copy and conv_diff!/BDIM! run as separate passes (slower). */
+  float *us;
 } wl_sim_desc;
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc);
 int wl_sim_destroy(wl_sim* s);
-float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sigma","V","mu0","mu1" */
+float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sigma","V","mu0","mu1","us" (current roles) */
 wl_mg* wl_sim_pois(wl_sim* s);
 int wl_sim_grid(const wl_sim* s, wl_grid* out);
 int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀ BC, (src/Flow.jl:141-145) after the caller filled u */
@@ -191,6 +198,7 @@ int wl_sim_mom_step(wl_sim* s, void* stream);           /* mom_step!(flow,pois):
 int wl_sim_dt(const wl_sim* s, float* host_out, int cap);      /* flow.Δt (host vector, src/Flow.jl:127) */
 double wl_sim_time(const wl_sim* s);                    /* time(flow) = sum(Δt[1:end-1]) :174 */
 float wl_sim_dt_last(const wl_sim* s);                 /* Δt[end] */
+int wl_sim_set_dt_last(wl_sim* s, float dt);           /* Δt[end] = dt: the host owns flow.Δt (src/Flow.jl:127) and may have changed it */
 /* sub-phases for parity tests: 0 u⁰.=u;scale_u!(0) 1 mom_predict! 2 mom_project!(1) 3 mom_correct! 4 mom_project!(.5) 5 push!(Δt,CFL) */
 int wl_sim_phase(wl_sim* s, int phase, void* stream);
 /* analytic initial conditions evaluated on device (apply!(u0,u), src/Flow.jl:81-83): kind 0 = uBC tuple,

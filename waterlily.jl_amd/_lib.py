@@ -41,7 +41,7 @@ class wl_sim_desc(C.Structure):
     _fields_ = [("D", C.c_int32), ("dims", C.c_int32 * 3), ("uBC", C.c_float * 3), ("nu", C.c_float), ("dt0", C.c_float),
                 ("perdir_mask", C.c_uint32), ("exitBC", C.c_int32), ("scheme", C.c_int32), ("has_body", C.c_int32),
                 ("u", C.c_void_p), ("u0", C.c_void_p), ("f", C.c_void_p), ("p", C.c_void_p), ("sigma", C.c_void_p),
-                ("V", C.c_void_p), ("mu0", C.c_void_p), ("mu1", C.c_void_p)]
+                ("V", C.c_void_p), ("mu0", C.c_void_p), ("mu1", C.c_void_p), ("us", C.c_void_p)]
 
 
 SENDRECV_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
@@ -123,6 +123,7 @@ SIGNATURES = {
     "wl_sim_dt": (i32, [P, C.POINTER(f32), i32]),
     "wl_sim_time": (f64, [P]),
     "wl_sim_dt_last": (f32, [P]),
+    "wl_sim_set_dt_last": (i32, [P, f32]),
     "wl_sim_phase": (i32, [P, i32, P]),
     "wl_sim_apply_ic": (i32, [P, i32, P]),
     "wl_sim_measure_sphere": (i32, [P, C.POINTER(f32), f32, f32, P]),

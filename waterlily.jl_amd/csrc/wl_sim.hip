@@ -531,7 +531,8 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   float* given[8] = {desc->u, desc->u0, desc->f, desc->p, desc->sigma, desc->V, desc->mu0, desc->mu1};
   const size_t sz[8] = {nc * D, nc * D, nc * D, nc, nc, nc * D, nc * D, nc * D * D};
   size_t total = 0;
-  const bool want_us = !desc->u && !desc->u0 && !desc->exitBC;   // spare velocity array of the out-of-place fused kernels
+  const bool none = !desc->u && !desc->u0, all3 = desc->u && desc->u0 && desc->us;
+  const bool want_us = none && !desc->us && !desc->exitBC;   // spare velocity array of the out-of-place fused kernels (handle-owned)
   if (want_us) total += nc * D;
   total += nc;   // ps
   for (int q = 0; q < 8; q++) if (!given[q] && !(q == 7 && !desc->has_body) && !(q == 5 && !desc->has_body)) total += sz[q];
@@ -543,9 +544,10 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     else { *ptrs[q] = pcur; pcur += sz[q]; }
   }
   if (want_us) { s->us = pcur; pcur += nc * D; }
+  else if (desc->us && (none || all3) && !desc->exitBC) s->us = desc->us;   // caller-owned spare: the roles of {u,u0,us} rotate (wlhip.h)
   s->ps = pcur; pcur += nc;
   s->dt.assign(1, desc->dt0);
-  s->swap_ok = !desc->u && !desc->u0 && !desc->exitBC;
+  s->swap_ok = (none || all3) && !desc->exitBC;
   // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
   if (!desc->mu0) {
     int rc = wl::fill(s->mu0, 1.f, nc * D, 0); const float zero[3] = {0, 0, 0};
@@ -568,6 +570,7 @@ float* wl_sim_field(wl_sim* s, const char* name) {
   if (n == "V" || n == "mu1" || n == "mu0") s->mask_valid = false;
   if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") return s->p;
   if (n == "sigma") return s->sigma; if (n == "V") return s->V; if (n == "mu0") return s->mu0; if (n == "mu1") return s->mu1;
+  if (n == "us") return s->us;
   return nullptr;
 }
 wl_mg* wl_sim_pois(wl_sim* s) { return s->mg; }
@@ -625,6 +628,7 @@ int wl_accelerate(float* r, const wl_grid* g, const float* a, void* st) {
 int wl_sim_mom_step(wl_sim* s, void* st) { return s->mom_step(wl_stream(st)); }
 int wl_sim_dt(const wl_sim* s, float* out, int cap) { const int n = (int)s->dt.size(); for (int k = 0; k < n && k < cap; k++) out[k] = s->dt[(size_t)k]; return n; }
 float wl_sim_dt_last(const wl_sim* s) { return s->dt.back(); }
+int wl_sim_set_dt_last(wl_sim* s, float dt) { WL_CHECK(s && dt > 0.f, "bad Δt"); s->dt.back() = dt; return 0; }
 double wl_sim_time(const wl_sim* s) { float t = 0.f; for (size_t k = 0; k + 1 < s->dt.size(); k++) t += s->dt[k]; return (double)t; }
 int wl_sim_phase(wl_sim* s, int phase, void* st) {
   hipStream_t q = wl_stream(st);
