@@ -170,6 +170,10 @@ typedef struct wl_sim_desc {
   float *us;
 } wl_sim_desc;
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc);
+/* the same on an EXISTING multigrid handle (wl_mg_create on desc->p, desc->mu0, desc->sigma): the Simulation constructor of the
+   reference builds the AbstractPoisson first (pois_ctor, src/WaterLily.jl:96-105) and mom_step!(flow,pois) receives both.  The wl_mg
+   stays the caller's (destroy the wl_sim first). */
+int wl_sim_create_on(wl_sim** out, const wl_sim_desc* desc, wl_mg* mg);
 int wl_sim_destroy(wl_sim* s);
 float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sigma","V","mu0","mu1","us" (current roles) */
 wl_mg* wl_sim_pois(wl_sim* s);

@@ -52,8 +52,15 @@ class CallerOwnedSim:
         d.nu, d.dt0, d.perdir_mask, d.exitBC, d.scheme, d.has_body = float(nu), 0.25, 0, int(exitBC), 0, int(body is not None)
         for name in ("u", "u0", "f", "p", "sigma", "V", "mu0", "mu1") + (("us",) if with_spare else ()):
             setattr(d, name, w.core.ptr(self.arr[name]).value)
+        # pois_ctor(flow) = MultiLevelPoisson(flow.p, flow.μ₀, flow.σ) -> wl_mg_create; the composite adopts it at the first mom_step!
+        from waterlily_jl_amd.core import sgrid
+        g0 = sgrid(self.arr["p"])
+        mg = C.c_void_p()
+        check(self.lib.wl_mg_create(C.byref(mg), w.core.ptr(self.arr["p"]), w.core.ptr(self.arr["mu0"]), w.core.ptr(self.arr["sigma"]), C.byref(g0), 0, 10))
+        self.mg = mg
         h = C.c_void_p()
-        check(self.lib.wl_sim_create(C.byref(h), C.byref(d)))               # pois_ctor(flow) -> HipMultiLevel: the handle of the composite
+        check(self.lib.wl_sim_create_on(C.byref(h), C.byref(d), mg))
+        assert self.lib.wl_sim_pois(h) == mg.value
         self.h = h
         self.dt = [np.float32(0.25)]
         self._ptr2name = {self.arr[k].data_ptr(): k for k in self.role}
@@ -76,7 +83,8 @@ class CallerOwnedSim:
         return [int(v) for v in out[:k]]
 
     def close(self):
-        self.check(self.lib.wl_sim_destroy(self.h))
+        self.check(self.lib.wl_sim_destroy(self.h))          # the wl_sim first: it uses the wl_mg
+        self.check(self.lib.wl_mg_destroy(self.mg))
 
 
 @pytest.mark.parametrize("dims", [(64, 64, 64), (96, 48, 40), (48, 40)])

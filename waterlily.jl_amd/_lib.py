@@ -110,6 +110,7 @@ SIGNATURES = {
     "wl_mg_history": (i32, [P, C.POINTER(C.c_int16), i32]),
     "wl_mg_last_log": (i32, [P, C.POINTER(f64), C.POINTER(f64), C.POINTER(f64), i32]),
     "wl_sim_create": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc)]),
+    "wl_sim_create_on": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc), P]),
     "wl_sim_destroy": (i32, [P]),
     "wl_sim_field": (P, [P, C.c_char_p]),
     "wl_sim_pois": (P, [P]),

@@ -292,7 +292,8 @@ struct wl_sim {
   float acc0[3] = {0, 0, 0}, acc1[3] = {0, 0, 0};   // at t₀ (predictor) and t₁ (corrector)
   float* us = nullptr;       // spare velocity array: the fused corrector writes here, then u and us trade places
   std::vector<float> dt;
-  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); if (farmask) (void)hipFree(farmask); if (mnear) (void)hipFree(mnear); if (mneedf) (void)hipFree(mneedf); if (mm0var) (void)hipFree(mm0var); }
+  bool own_mg = true;        // false: the multigrid handle belongs to the caller (wl_sim_create_on)
+  ~wl_sim() { if (u_pending && comm && comm->cs) (void)hipStreamSynchronize(comm->cs); if (own_mg) delete mg; if (own) (void)hipFree(own); if (exit_sc) (void)hipFree(exit_sc); if (farmask) (void)hipFree(farmask); if (mnear) (void)hipFree(mnear); if (mneedf) (void)hipFree(mneedf); if (mm0var) (void)hipFree(mm0var); }
 
   // BC!(u) on the physical faces this rank holds, then the z-halo planes (depth 2: QUICK reads f[I-2δ], src/Flow.jl:8)
   // On slabs the exchange runs on the communicator's own stream; the compute stream waits for it (sync_u) only where the halo
@@ -514,7 +515,7 @@ int wl_L2_inside(const float* a, const wl_grid* g, double* out, void* st) {
   return wl::read_results(ws, out, 1, nullptr, 0, s);
 }
 
-static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm) {
+static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm, wl_mg* adopt = nullptr) {
   WL_CHECK(out && desc, "null pointer"); WL_CHECK(desc->D == 2 || desc->D == 3, "D must be 2 or 3");
   WL_TRY(wl_ctx_ensure());
   const bool slab = comm && comm->size > 1;
@@ -555,13 +556,21 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     if (rc == 0) rc = wl::halo(s->comm, s->mu0, s->G, D, 2, 0);
     if (rc != 0) { delete s; return rc; }
   }
-  s->mg = new wl_mg();
-  int rc = s->mg->build(s->p, s->mu0, s->sigma, s->g, desc->perdir_mask, 10, s->comm);   // pois_ctor default  src/WaterLily.jl:97
-  if (rc != 0) { delete s; *out = nullptr; return rc; }
+  if (adopt) {   // the caller's MultiLevelPoisson (wl_mg_create on the same p, μ₀, σ): used, not owned
+    if (slab || adopt->lv.empty() || adopt->lv[0].x != s->p || adopt->lv[0].L != s->mu0 || adopt->lv[0].z != s->sigma) {
+      delete s; *out = nullptr; wl_set_error("wl_sim_create_on: the wl_mg handle was not built on this flow's p, mu0, sigma"); return WL_EINVAL;
+    }
+    s->mg = adopt; s->own_mg = false;
+  } else {
+    s->mg = new wl_mg();
+    int rc = s->mg->build(s->p, s->mu0, s->sigma, s->g, desc->perdir_mask, 10, s->comm);   // pois_ctor default  src/WaterLily.jl:97
+    if (rc != 0) { delete s; *out = nullptr; return rc; }
+  }
   s->mg->store_eps = false;   // p.ϵ is pure scratch on the time-step path
   *out = s; return 0;
 }
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) { return sim_create_common(out, desc, nullptr); }
+int wl_sim_create_on(wl_sim** out, const wl_sim_desc* desc, wl_mg* mg) { WL_CHECK(mg, "null wl_mg"); return sim_create_common(out, desc, nullptr, mg); }
 int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm) { return sim_create_common(out, desc, comm); }
 int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
 float* wl_sim_field(wl_sim* s, const char* name) {

@@ -1,20 +1,29 @@
 # WaterLilyHIPExt — Julia-side binding of libwlhip.so (include/wlhip.h) for WaterLily.jl.
 #
-# STATUS: written against the reference's sources, NOT executed — no Julia runtime exists in the build
-# container or on the GPU box (SURVEY.md §0).  Everything with logic lives in the library; this file is
-# mechanical dispatch glue: one array type + one method per hot-path function, `ccall`ing the C ABI.
-# It imitates the pattern of ext/WaterLilyAMDGPUExt.jl (array type selects the backend) but does not use
-# AMDGPU.jl / KernelAbstractions.
+# STATUS: written against the reference's sources and desk-checked call by call, NOT executed — no Julia runtime exists in the
+# build container or on the GPU box (SURVEY.md §0).  What CAN be checked here is checked: tests/test_julia_binding.py asserts
+# that every `@loop` / `@inside` / broadcast / reduction site reachable from `Simulation(...)` + `sim_step!` in the reference
+# (the committed list julia/sites.json, verified against /root/reference/src line by line) has an intercepting method in this
+# file, that every `ccall` names a symbol include/wlhip.h declares with the declared number of arguments, and
+# tests/test_gpu_callerowned.py drives the SAME C-ABI call sequence (caller-owned arrays → wl_mg_create → wl_sim_create_on →
+# wl_sim_mom_step → role read-back) against the handle-owned path, bit for bit.
+#
+# Everything with logic lives in the library; this file is dispatch glue: one array type and one method per function of the
+# hot path, `ccall`ing the C ABI.  It imitates the pattern of ext/WaterLilyAMDGPUExt.jl (the array type selects the backend)
+# but does not use AMDGPU.jl or KernelAbstractions kernels.
 #
 # Use:   using WaterLily, WaterLilyHIP
 #        sim = Simulation((512,512,512),(0,0,0),512; U=1, ν=512/1600, T=Float32, mem=HipArray)
-#        sim_step!(sim; remeasure=false)
+#        sim_step!(sim; remeasure=false)          # → wl_sim_mom_step, the path bench.py times
 module WaterLilyHIPExt
 
 using WaterLily
-import WaterLily: BC!, perBC!, exitBC!, conv_diff!, BDIM!, scale_u!, CFL, L₂, mom_step!, mom_project!,
+using KernelAbstractions
+using LinearAlgebra
+import WaterLily: BC!, perBC!, exitBC!, apply!, conv_diff!, accelerate!, BDIM!, scale_u!, CFL, L₂, mom_step!, mom_project!, measure!,
                   set_diag!, update!, mult!, residual!, increment!, Jacobi!, GaussSeidelRB!, pcg!, restrict!, prolongate!,
-                  restrictL!, solver!, Vcycle!, L₁, L∞, quick, vanLeer, cds, Flow, Poisson, MultiLevelPoisson, AbstractPoisson
+                  restrictL!, solver!, L₁, L∞, quick, vanLeer, cds, loc, Flow, Poisson, MultiLevelPoisson, AbstractPoisson,
+                  AbstractFlow, AbstractBody, NoBody
 
 const libwlhip = get(ENV, "WLHIP_LIB", "libwlhip.so")
 
@@ -28,38 +37,110 @@ end
 __init__() = chk(ccall((:wl_init, libwlhip), Cint, (Cint,), 0))   # like ext/WaterLilyAMDGPUExt.jl:11
 
 # ---- the array type: dense column-major Float32 in HBM, byte-identical to the Julia Array layout --------
+# `ptr` is mutable on purpose: the composite time step permutes the roles of the three velocity buffers {u, u⁰, spare}
+# (include/wlhip.h, wl_sim_desc.us) and the binding re-points flow.u / flow.u⁰ after every step.  `owned` = this object's
+# finalizer frees the buffer it points at when it dies (views of library-owned level arrays are not owned).
 mutable struct HipArray{T,N} <: AbstractArray{T,N}
     ptr::Ptr{T}
     dims::NTuple{N,Int}
+    owned::Bool
     function HipArray{T,N}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N}
-        T === Float32 || error("the HIP path computes in Float32")
+        T === Float32 || error("the HIP path computes in Float32 (got $T)")
         p = Ref{Ptr{Cvoid}}()
-        chk(ccall((:wl_malloc, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, prod(dims) * sizeof(T)))
-        a = new{T,N}(Ptr{T}(p[]), dims)
-        finalizer(x -> ccall((:wl_free, libwlhip), Cint, (Ptr{Cvoid},), x.ptr), a)   # Julia owns lifetimes (SURVEY §8b)
+        chk(ccall((:wl_malloc, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, max(prod(dims), 1) * sizeof(T)))
+        a = new{T,N}(Ptr{T}(p[]), dims, true)
+        finalizer(x -> (x.owned && ccall((:wl_free, libwlhip), Cint, (Ptr{Cvoid},), x.ptr); nothing), a)   # Julia owns lifetimes (SURVEY §8b)
     end
+    HipArray{T,N}(p::Ptr{T}, dims::NTuple{N,Int}) where {T,N} = new{T,N}(p, dims, false)   # non-owning view of a library array
 end
+HipArray{T}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N} = HipArray{T,N}(undef, dims)
+HipArray{T}(::UndefInitializer, dims::Int...) where {T} = HipArray{T,length(dims)}(undef, dims)
+nbytes(a::HipArray{T}) where {T} = length(a) * sizeof(T)
+h2d!(d::HipArray, h::Array) = (chk(ccall((:wl_h2d, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), d.ptr, h, nbytes(d), C_NULL)); d)
+d2h!(h::Array, d::HipArray) = (chk(ccall((:wl_d2h, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), h, d.ptr, nbytes(d), C_NULL)); h)
 # `zeros(T,Ng) |> mem` / `Array{T}(undef,…) |> mem`   (src/Flow.jl:139,143-144): mem(::Array) does the H2D copy
-function HipArray(a::Array{T,N}) where {T,N}
-    d = HipArray{T,N}(undef, size(a))
-    chk(ccall((:wl_h2d, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), d.ptr, a, sizeof(a), C_NULL)); d
-end
+HipArray(a::Array{T,N}) where {T,N} = h2d!(HipArray{T,N}(undef, size(a)), a)
+HipArray(a::AbstractArray) = HipArray(Array(a))
 Base.size(a::HipArray) = a.dims
-Base.similar(a::HipArray{T}, dims::Dims{N}) where {T,N} = HipArray{T,N}(undef, dims)
-Base.Array(a::HipArray{T,N}) where {T,N} = (h = Array{T,N}(undef, a.dims);
-    chk(ccall((:wl_d2h, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), h, a.ptr, sizeof(h), C_NULL)); h)
-Base.copyto!(d::HipArray, s::HipArray) = (chk(ccall((:wl_d2d, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), d.ptr, s.ptr, length(s) * 4, C_NULL)); d)
-Base.copy(a::HipArray) = copyto!(similar(a, size(a)), a)
-Base.fill!(a::HipArray, v) = (chk(ccall((:wl_fill, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), a.ptr, v, length(a), C_NULL)); a)
-# scalar getindex/setindex! (tests use GPUArrays.@allowscalar): one-element transfers
-Base.getindex(a::HipArray{T}, i::Int) where T = (r = Ref{T}(); chk(ccall((:wl_d2h, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), r, a.ptr + (i - 1) * sizeof(T), sizeof(T), C_NULL)); r[])
-Base.setindex!(a::HipArray{T}, v, i::Int) where T = (r = Ref{T}(v); chk(ccall((:wl_h2d, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), a.ptr + (i - 1) * sizeof(T), r, sizeof(T), C_NULL)); v)
+Base.similar(a::HipArray, ::Type{T}, dims::Dims{N}) where {T,N} = HipArray{T,N}(undef, dims)
+Base.Array(a::HipArray{T,N}) where {T,N} = d2h!(Array{T,N}(undef, a.dims), a)
+Base.collect(a::HipArray) = Array(a)
+function Base.copyto!(d::HipArray, s::HipArray)
+    @assert length(d) == length(s)
+    chk(ccall((:wl_d2d, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), d.ptr, s.ptr, nbytes(s), C_NULL)); d
+end
+Base.copyto!(d::HipArray{T}, s::Array{T}) where {T} = (@assert length(d) == length(s); h2d!(d, s))
+Base.copyto!(d::Array{T}, s::HipArray{T}) where {T} = (@assert length(d) == length(s); d2h!(d, s))
+Base.copy(a::HipArray) = copyto!(similar(a), a)
+Base.fill!(a::HipArray, v) = (chk(ccall((:wl_fill, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), a.ptr, Cfloat(v), length(a), C_NULL)); a)
+# scalar getindex/setindex! (tests use GPUArrays.@allowscalar): one-element transfers — also what a non-intercepted @loop falls
+# back to (see get_backend below): correct, slow, meant for the small arrays of tests
 Base.IndexStyle(::Type{<:HipArray}) = IndexLinear()
-# reductions and broadcasts the path uses (src/Poisson.jl:95,189-191; src/Flow.jl:39,157,225,230,236)
-Base.sum(a::HipArray) = (r = Ref{Cdouble}(); chk(ccall((:wl_sum, libwlhip), Cint, (Ptr{Cfloat}, Csize_t, Ref{Cdouble}, Ptr{Cvoid}), a.ptr, length(a), r, C_NULL)); Float32(r[]))
+Base.getindex(a::HipArray{T}, i::Int) where {T} = (r = Ref{T}(); chk(ccall((:wl_d2h, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), r, a.ptr + (i - 1) * sizeof(T), sizeof(T), C_NULL)); r[])
+Base.setindex!(a::HipArray{T}, v, i::Int) where {T} = (r = Ref{T}(v); chk(ccall((:wl_h2d, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), a.ptr + (i - 1) * sizeof(T), r, sizeof(T), C_NULL)); v)
+Base.show(io::IO, ::MIME"text/plain", a::HipArray) = print(io, join(size(a), "×"), " HipArray{", eltype(a), "} @", a.ptr)
+Base.show(io::IO, a::HipArray) = print(io, join(size(a), "×"), " HipArray{", eltype(a), "}")
+
+# A `@loop` of the reference that no method below intercepts reaches `get_backend(first array)` (src/core.jl:142).  The host-staging
+# fallback: the KernelAbstractions CPU backend runs the kernel on host threads and every element access is a one-element transfer
+# through getindex/setindex! above.  Nothing on the time-step path takes this route (julia/sites.json lists every site and its
+# interceptor); it exists so that user code and the reference's small tests keep working.
+KernelAbstractions.get_backend(::HipArray) = KernelAbstractions.CPU()
+
+# ---- broadcasts on the path: `a .= s`, `a .= b`, `a .*= s`, `a ./= s` (src/Flow.jl:39,157,225,230; src/Body.jl:29) ----------
+# `materialize!(dest, bc)` ends in copyto!(dest, ::Broadcasted): the four forms go to wl_fill / wl_d2d / wl_scale / wl_div_scalar,
+# anything else is evaluated on host copies and written back (host staging).
+hostarg(x::HipArray) = Array(x)
+hostarg(x::Base.Broadcast.Broadcasted) = Base.Broadcast.Broadcasted(x.f, map(hostarg, x.args))
+hostarg(x) = x
+function bc_copyto!(dest::HipArray{T}, bc::Base.Broadcast.Broadcasted) where {T}
+    f, args = bc.f, bc.args
+    if f === identity && length(args) == 1
+        x = args[1]
+        x isa Number && return fill!(dest, x)                                       # a .= s
+        x isa Base.RefValue && x[] isa Number && return fill!(dest, x[])
+        x isa HipArray && size(x) == size(dest) && return copyto!(dest, x)          # a .= b      (u⁰ .= u)
+        x isa Array && size(x) == size(dest) && return copyto!(dest, convert(Array{T}, x))
+    elseif f === (*) && length(args) == 2 && args[1] === dest && args[2] isa Number
+        chk(ccall((:wl_scale, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), dest.ptr, Cfloat(args[2]), length(dest), C_NULL)); return dest   # a .*= s
+    elseif f === (*) && length(args) == 2 && args[2] === dest && args[1] isa Number
+        chk(ccall((:wl_scale, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), dest.ptr, Cfloat(args[1]), length(dest), C_NULL)); return dest
+    elseif f === (/) && length(args) == 2 && args[1] === dest && args[2] isa Number
+        chk(ccall((:wl_div_scalar, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), dest.ptr, Cfloat(args[2]), length(dest), C_NULL)); return dest   # a ./= s
+    end
+    h = Array(dest)                                                                 # host staging for every other form
+    Base.Broadcast.materialize!(h, Base.Broadcast.Broadcasted(f, map(hostarg, args)))
+    copyto!(dest, h)
+end
+Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted) = bc_copyto!(dest, bc)
+Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted{Nothing}) = bc_copyto!(dest, bc)      # (resolves the ambiguities with Base's
+Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted{<:Base.Broadcast.AbstractArrayStyle{0}}) = bc_copyto!(dest, bc)   #  generic loop and scalar fill)
+# out-of-place broadcasts (`a .+ b`, perturb!'s `randn(...)*U |> mem`) are evaluated on the host and uploaded
+struct HipStyle <: Base.Broadcast.AbstractArrayStyle{Any} end
+HipStyle(::Val) = HipStyle()
+Base.Broadcast.BroadcastStyle(::Type{<:HipArray}) = HipStyle()
+Base.Broadcast.BroadcastStyle(::HipStyle, ::Base.Broadcast.AbstractArrayStyle) = HipStyle()
+Base.copy(bc::Base.Broadcast.Broadcasted{HipStyle}) = HipArray(Base.Broadcast.materialize(Base.Broadcast.Broadcasted(bc.f, map(hostarg, bc.args))))
+
+# ---- reductions the path uses (src/Poisson.jl:95,189-191; src/Flow.jl:236; src/core.jl:229,231) -----------------------------
+function sumdev(a::HipArray)
+    r = Ref{Cdouble}(); chk(ccall((:wl_sum, libwlhip), Cint, (Ptr{Cfloat}, Csize_t, Ref{Cdouble}, Ptr{Cvoid}), a.ptr, length(a), r, C_NULL)); r[]
+end
+function absnorms(a::HipArray)
+    s = Ref{Cdouble}(); m = Ref{Cfloat}()
+    chk(ccall((:wl_sum_abs_max_abs, libwlhip), Cint, (Ptr{Cfloat}, Csize_t, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}), a.ptr, length(a), s, m, C_NULL)); (s[], m[])
+end
+Base.sum(a::HipArray{T}) where {T} = T(sumdev(a))
+Base.sum(::typeof(abs), a::HipArray{T}) where {T} = T(absnorms(a)[1])
+Base.maximum(::typeof(abs), a::HipArray) = absnorms(a)[2]
 Base.maximum(a::HipArray) = (r = Ref{Cfloat}(); chk(ccall((:wl_max, libwlhip), Cint, (Ptr{Cfloat}, Csize_t, Ref{Cfloat}, Ptr{Cvoid}), a.ptr, length(a), r, C_NULL)); r[])
-scale!(a::HipArray, s) = chk(ccall((:wl_scale, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), a.ptr, s, length(a), C_NULL))
-unscale!(a::HipArray, s) = chk(ccall((:wl_div_scalar, libwlhip), Cint, (Ptr{Cfloat}, Cfloat, Csize_t, Ptr{Cvoid}), a.ptr, s, length(a), C_NULL))
+function LinearAlgebra.dot(a::HipArray{T}, b::HipArray{T}) where {T}
+    r = Ref{Cdouble}(); chk(ccall((:wl_dot, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Csize_t, Ref{Cdouble}, Ptr{Cvoid}), a.ptr, b.ptr, length(a), r, C_NULL)); T(r[])
+end
+# any other reduction (sum over dims, mapreduce with a closure, …): on a host copy
+Base.mapreduce(f, op, a::HipArray; kw...) = mapreduce(f, op, Array(a); kw...)
+Base.sum(f, a::HipArray; kw...) = sum(f, Array(a); kw...)
+Base.sum(::Type{T}, a::HipArray; kw...) where {T} = sum(T, Array(a); kw...)
 
 # ---- wl_grid of a single-domain array ---------------------------------------------------------------------
 struct WlGrid; D::Int32; nx::Int32; ny::Int32; nz::Int32; k0::Int32; k1::Int32; gk::Int32; gnz::Int32; end
@@ -68,18 +149,22 @@ grid(dims::NTuple{3}) = WlGrid(3, dims[1], dims[2], dims[3], 1, dims[3] - 1, 0, 
 sgrid(a::HipArray) = Ref(grid(size(a)))
 vgrid(a::HipArray) = Ref(grid(Base.front(size(a))))
 pmask(perdir) = UInt32(sum((1 << (j - 1) for j in perdir); init=0))
-scheme(λ) = λ === quick ? 0 : λ === vanLeer ? 1 : λ === cds ? 2 : error("λ must be quick, vanLeer or cds on the HIP path")
+scheme(λ) = λ === quick ? Int32(0) : λ === vanLeer ? Int32(1) : λ === cds ? Int32(2) : error("λ must be quick, vanLeer or cds on the HIP path")
+pad3(v) = ntuple(i -> i <= length(v) ? Cfloat(v[i]) : 0f0, 3)
 
 const HA = HipArray{Float32}
 const HFlow = Flow{D,Float32,<:HA} where D
 const HPois = Poisson{Float32,<:HA}
-const HML = MultiLevelPoisson{Float32,<:HA}
 
 # ---- core.jl ------------------------------------------------------------------------------------------------
-# BC!(a,U::tuple,saveexit,perdir,t)  src/core.jl:200  (Function-valued uBC falls back to host staging — SURVEY §8b)
+# apply!(f,c) src/core.jl:134-145 (Flow ctor :140): the closure cannot cross the C ABI — evaluate it on a host array, upload
+function apply!(f, c::HipArray{T,N}) where {T,N}
+    h = Array{T,N}(undef, size(c)); WaterLily.apply!(f, h); copyto!(c, h); c
+end
+# BC!(a,U::tuple,saveexit,perdir,t)  src/core.jl:200
 BC!(a::HA, U::Union{Tuple,AbstractVector}, saveexit=false, perdir=(), t=0) =
     chk(ccall((:wl_bc_vec, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{NTuple{3,Cfloat}}, Cint, Cuint, Ptr{Cvoid}),
-              a.ptr, vgrid(a), ntuple(i -> i <= length(U) ? Cfloat(U[i]) : 0f0, 3), saveexit, pmask(perdir), C_NULL))
+              a.ptr, vgrid(a), Ref(pad3(U)), Cint(saveexit), pmask(perdir), C_NULL))
 # BC!(a,uBC::Function,…) src/core.jl:201-219: the closure is evaluated on the host over the boundary shell (two layers per side, all
 # the kernel reads) and handed over as a table; the device applies the reference's sequential edge/corner semantics.
 function BC!(a::HA, uBC::Function, saveexit=false, perdir=(), t=0)
@@ -90,111 +175,200 @@ function BC!(a::HA, uBC::Function, saveexit=false, perdir=(), t=0)
         for I in WaterLily.slice(N, s, j); tab[I, i] = uBC(i, loc(i, I, T), t); end
     end
     Ub = HipArray(tab)
-    chk(ccall((:wl_bc_vec_fn, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cuint, Ptr{Cvoid}), a.ptr, Ub.ptr, vgrid(a), saveexit, pmask(perdir), C_NULL))
+    chk(ccall((:wl_bc_vec_fn, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cuint, Ptr{Cvoid}), a.ptr, Ub.ptr, vgrid(a), Cint(saveexit), pmask(perdir), C_NULL))
+    chk(ccall((:wl_stream_sync, libwlhip), Cint, (Ptr{Cvoid},), C_NULL))     # Ub is a temporary
 end
 # accelerate!(r,t,g,U) src/Flow.jl:69-73 for closures: tabulate g(i,x,t)+∂ₜU(i,x,t) on the host, add on the device
-function WaterLily.accelerate!(r::HA, t, f::Function)
+function accelerate!(r::HA, t, f::Function)
     T = eltype(r); tab = zeros(T, size(r))
     for Ii in CartesianIndices(tab); tab[Ii] = f(last(Ii), loc(Ii, T), t); end
     G = HipArray(tab)
     chk(ccall((:wl_accelerate_field, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), r.ptr, G.ptr, vgrid(r), C_NULL))
+    chk(ccall((:wl_stream_sync, libwlhip), Cint, (Ptr{Cvoid},), C_NULL))
 end
 perBC!(a::HA, perdir::Tuple) = isempty(perdir) ? nothing :
     chk(ccall((:wl_bc_per_scalar, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cuint, Ptr{Cvoid}), a.ptr, sgrid(a), pmask(perdir), C_NULL))
-exitBC!(u::HA, u⁰::HA, Δt) = chk(ccall((:wl_exit_bc, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}), u.ptr, u⁰.ptr, vgrid(u), Δt, C_NULL))
+exitBC!(u::HA, u⁰::HA, Δt) = chk(ccall((:wl_exit_bc, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}), u.ptr, u⁰.ptr, vgrid(u), Cfloat(Δt), C_NULL))
 L₂(a::HA) = (r = Ref{Cdouble}(); chk(ccall((:wl_L2_inside, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{Cdouble}, Ptr{Cvoid}), a.ptr, sgrid(a), r, C_NULL)); r[])   # ext/WaterLilyAMDGPUExt.jl:18
 
-# ---- Flow.jl -------------------------------------------------------------------------------------------------
+# ---- Flow.jl: leaf operations (the reference's mom_predict!/mom_correct! run unchanged on top of these) -------------------------
 conv_diff!(r::HA, u::HA, Φ::HA, λ::F; ν=0.1, perdir=()) where {F} =
     chk(ccall((:wl_conv_diff, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Cuint, Cint, Ptr{Cvoid}),
-              r.ptr, u.ptr, Φ.ptr, vgrid(u), ν, pmask(perdir), scheme(λ), C_NULL))
+              r.ptr, u.ptr, Φ.ptr, vgrid(u), Cfloat(ν), pmask(perdir), scheme(λ), C_NULL))
 BDIM!(a::HFlow) = chk(ccall((:wl_bdim, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Cfloat, Cfloat, Ptr{Cvoid}),
                           a.u.ptr, a.u⁰.ptr, a.f.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, vgrid(a.u), a.Δt[end], 1f0, 1f0, C_NULL))
-scale_u!(a::HFlow, s) = chk(ccall((:wl_scale_u, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}), a.u.ptr, vgrid(a.u), s, C_NULL))
+scale_u!(a::HFlow, s) = chk(ccall((:wl_scale_u, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}), a.u.ptr, vgrid(a.u), Cfloat(s), C_NULL))
 function CFL(a::HFlow; Δt_max=10)
     r = Ref{Cfloat}()
-    chk(ccall((:wl_cfl, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Cfloat, Ref{Cfloat}, Ptr{Cvoid}), a.u.ptr, a.σ.ptr, sgrid(a.σ), a.ν, Δt_max, r, C_NULL)); r[]
+    chk(ccall((:wl_cfl, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Cfloat, Ref{Cfloat}, Ptr{Cvoid}), a.u.ptr, a.σ.ptr, sgrid(a.σ), a.ν, Cfloat(Δt_max), r, C_NULL)); r[]
 end
 function mom_project!(a::HFlow, b::AbstractPoisson, w, t)        # src/Flow.jl:223-232 on device arrays
     dt = Float32(w) * a.Δt[end]
-    chk(ccall((:wl_div, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), b.z.ptr, a.u.ptr, sgrid(b.z), C_NULL)); scale!(b.x, dt)
+    chk(ccall((:wl_div, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), b.z.ptr, a.u.ptr, sgrid(b.z), C_NULL))
+    b.x .*= dt
     solver!(b)
     chk(ccall((:wl_project, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), a.u.ptr, b.L.ptr, b.x.ptr, sgrid(b.x), C_NULL))
-    unscale!(b.x, dt); BC!(a.u, a.uBC, a.exitBC, a.perdir, t)
+    b.x ./= dt
+    BC!(a.u, a.uBC, a.exitBC, a.perdir, t)
 end
-# mom_step!, mom_predict!, mom_correct! of the reference run UNCHANGED on top of these methods (u⁰ .= u → copyto!).
 
-# ---- Poisson.jl / MultiLevelPoisson.jl --------------------------------------------------------------------------
+# ---- Poisson.jl (single level) -----------------------------------------------------------------------------------------------
 set_diag!(D::HA, iD::HA, L::HA) = chk(ccall((:wl_set_diag, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), D.ptr, iD.ptr, L.ptr, sgrid(D), C_NULL))
 mult!(p::HPois, x::HA) = (perBC!(x, p.perdir); chk(ccall((:wl_mult, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), p.z.ptr, p.L.ptr, p.D.ptr, x.ptr, sgrid(x), C_NULL)); p.z)
 residual!(p::HPois) = (perBC!(p.x, p.perdir); chk(ccall((:wl_residual, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}, Ptr{Cvoid}),
                                                       p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), C_NULL, C_NULL)))
 increment!(p::HPois; ω=1) = (perBC!(p.ϵ, p.perdir); chk(ccall((:wl_increment, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}),
-                                                             p.r.ptr, p.x.ptr, p.ϵ.ptr, p.L.ptr, p.D.ptr, sgrid(p.x), ω, C_NULL)))
+                                                             p.r.ptr, p.x.ptr, p.ϵ.ptr, p.L.ptr, p.D.ptr, sgrid(p.x), Cfloat(ω), C_NULL)))
 Jacobi!(p::HPois; it=1, ω=1) = chk(ccall((:wl_jacobi, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cfloat, Cuint, Ptr{Cvoid}),
-                                         p.ϵ.ptr, p.r.ptr, p.x.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), it, ω, pmask(p.perdir), C_NULL))
+                                         p.ϵ.ptr, p.r.ptr, p.x.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), Cint(it), Cfloat(ω), pmask(p.perdir), C_NULL))
 GaussSeidelRB!(p::HPois; it=4, ω=1) = chk(ccall((:wl_gsrb, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cfloat, Cuint, Ptr{Cvoid}),
-                                                p.ϵ.ptr, p.r.ptr, p.x.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), it, ω, pmask(p.perdir), C_NULL))
+                                                p.ϵ.ptr, p.r.ptr, p.x.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), Cint(it), Cfloat(ω), pmask(p.perdir), C_NULL))
 pcg!(p::HPois; it=6, kwargs...) = chk(ccall((:wl_pcg, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cint, Cuint, Ptr{Cvoid}),
-                                           p.ϵ.ptr, p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), it, pmask(p.perdir), C_NULL))   # src/Poisson.jl:166
+                                           p.ϵ.ptr, p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), Cint(it), pmask(p.perdir), C_NULL))   # src/Poisson.jl:166
 function solver!(p::HPois; tol=2e-3, itmx=1e3)                                                                                            # src/Poisson.jl:212
     n = Ref{Cint}()
     chk(ccall((:wl_poisson_solve, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cdouble, Cint, Cuint, Ref{Cint}, Ptr{Cdouble}, Ptr{Cfloat}, Ptr{Cvoid}),
-              p.ϵ.ptr, p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), tol, Int32(min(itmx, typemax(Int32))), pmask(p.perdir), n, C_NULL, C_NULL, C_NULL))
+              p.ϵ.ptr, p.r.ptr, p.x.ptr, p.z.ptr, p.L.ptr, p.D.ptr, p.iD.ptr, sgrid(p.x), Cdouble(tol), Cint(min(itmx, typemax(Int32))), pmask(p.perdir), n, C_NULL, C_NULL, C_NULL))
     push!(p.n, n[])
 end
-function norms(p::HPois)
+function norms(r::HA)
     l1 = Ref{Cdouble}(); li = Ref{Cfloat}()
-    chk(ccall((:wl_norms, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}, Ptr{Cvoid}), p.r.ptr, sgrid(p.r), l1, li, C_NULL, C_NULL)); (Float32(l1[]), li[])
+    chk(ccall((:wl_norms, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}, Ptr{Cvoid}), r.ptr, sgrid(r), l1, li, C_NULL, C_NULL)); (Float32(l1[]), li[])
 end
-L₁(p::HPois) = norms(p)[1]
-L∞(p::HPois) = norms(p)[2]
+L₁(p::HPois) = norms(p.r)[1]
+L∞(p::HPois) = norms(p.r)[2]
 restrict!(a::HA, b::HA, c) = chk(ccall((:wl_restrict, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), a.ptr, sgrid(a), b.ptr, sgrid(b), C_NULL))
 prolongate!(a::HA, b::HA, c) = chk(ccall((:wl_prolongate, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), a.ptr, sgrid(a), b.ptr, sgrid(b), C_NULL))
 restrictL!(a::HA, b::HA, c; perdir=()) = chk(ccall((:wl_restrictL, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cfloat}, Ref{WlGrid}, Cuint, Ptr{Cvoid}), a.ptr, vgrid(a), b.ptr, vgrid(b), pmask(perdir), C_NULL))
-# With the methods above the reference's own Vcycle!/solver!/update!/mom_step! drive the device unchanged.
-#
-# Fast path (what bench.py times): hand the whole solve / step to the library's composites, which fuse launches,
-# keep the convergence scalars on device and need one host read per V-cycle.  `pois_ctor` is the official hook
-# (src/WaterLily.jl:69-74,96-97):   Simulation(...; mem=HipArray, pois_ctor = flow -> HipMultiLevel(flow))
+
+# ---- MultiLevelPoisson.jl: the multigrid handle + the composite time step ----------------------------------------------------------
+# `MultiLevelPoisson(flow.p, flow.μ₀, flow.σ; perdir)` is the reference's default pois_ctor (src/WaterLily.jl:96-97).  For HipArrays
+# the constructor returns a HipMultiLevel: level storage, V-cycle and solver! live in the library (wl_mg); `levels` gives read access
+# to every level's arrays as non-owning HipArrays (the reference's tests read pois.levels[k].D etc.).
 mutable struct HipMultiLevel <: AbstractPoisson{Float32,HA,HA}
-    x::HA; L::HA; z::HA; n::Vector{Int16}; perdir::NTuple; handle::Ptr{Cvoid}
+    x::HA; L::HA; z::HA; n::Vector{Int16}; perdir::NTuple
+    handle::Ptr{Cvoid}          # wl_mg
+    sim::Ptr{Cvoid}             # wl_sim created on the flow's arrays at the first mom_step! (C_NULL before)
+    spare::Union{Nothing,HA}    # the third velocity buffer of the composite (wl_sim_desc.us)
+    flowkey::UInt               # objectid of the Flow the composite was created for
+    has_body::Bool
 end
-function HipMultiLevel(flow; perdir=flow.perdir, maxlevels=10)
+function MultiLevelPoisson(x::HipArray{Float32}, L::HipArray{Float32}, z::HipArray{Float32}; maxlevels=10, perdir=())
     h = Ref{Ptr{Cvoid}}()
-    chk(ccall((:wl_mg_create, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cuint, Cint), h, flow.p.ptr, flow.μ₀.ptr, flow.σ.ptr, sgrid(flow.p), pmask(perdir), maxlevels))
-    m = HipMultiLevel(flow.p, flow.μ₀, flow.σ, Int16[], perdir, h[])
-    finalizer(x -> ccall((:wl_mg_destroy, libwlhip), Cint, (Ptr{Cvoid},), x.handle), m)
+    chk(ccall((:wl_mg_create, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cuint, Cint), h, x.ptr, L.ptr, z.ptr, sgrid(x), pmask(perdir), Cint(maxlevels)))
+    m = HipMultiLevel(x, L, z, Int16[], perdir, h[], C_NULL, nothing, UInt(0), false)
+    finalizer(m) do y
+        y.sim != C_NULL && ccall((:wl_sim_destroy, libwlhip), Cint, (Ptr{Cvoid},), y.sim)      # the wl_sim first: it uses the wl_mg
+        ccall((:wl_mg_destroy, libwlhip), Cint, (Ptr{Cvoid},), y.handle)
+        nothing
+    end
 end
-update!(m::HipMultiLevel) = chk(ccall((:wl_mg_update, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), m.handle, C_NULL))
-function solver!(m::HipMultiLevel; tol=2e-3, itmx=32)
+HipMultiLevel(flow; perdir=flow.perdir, maxlevels=10) = MultiLevelPoisson(flow.p, flow.μ₀, flow.σ; maxlevels, perdir)
+struct HipLevel; L::HA; D::HA; iD::HA; x::HA; ϵ::HA; r::HA; z::HA; end
+function level(m::HipMultiLevel, l::Int)
+    g = Ref(WlGrid(0, 0, 0, 0, 0, 0, 0, 0))
+    chk(ccall((:wl_mg_level_grid, libwlhip), Cint, (Ptr{Cvoid}, Cint, Ref{WlGrid}), getfield(m, :handle), Cint(l - 1), g))
+    D = Int(g[].D); dims = D == 2 ? (Int(g[].nx), Int(g[].ny)) : (Int(g[].nx), Int(g[].ny), Int(g[].nz))
+    fld(name, d) = HipArray{Float32,length(d)}(ccall((:wl_mg_level_field, libwlhip), Ptr{Cfloat}, (Ptr{Cvoid}, Cint, Cstring), getfield(m, :handle), Cint(l - 1), name), d)
+    HipLevel(fld("L", (dims..., D)), fld("D", dims), fld("iD", dims), fld("x", dims), fld("eps", dims), fld("r", dims), fld("z", dims))
+end
+nlevels(m::HipMultiLevel) = Int(ccall((:wl_mg_nlevels, libwlhip), Cint, (Ptr{Cvoid},), getfield(m, :handle)))
+Base.getproperty(m::HipMultiLevel, s::Symbol) = s === :levels ? [level(m, l) for l in 1:nlevels(m)] : getfield(m, s)
+function update!(m::HipMultiLevel)                       # update!(pois) after measure!  src/WaterLily.jl:148
+    m.sim != C_NULL ? chk(ccall((:wl_sim_update, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), m.sim, C_NULL)) :
+                      chk(ccall((:wl_mg_update, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), m.handle, C_NULL))
+end
+function solver!(m::HipMultiLevel; tol=2e-3, itmx=32)    # src/MultiLevelPoisson.jl:108-128
     n = Ref{Cint}(); r1 = Ref{Cdouble}(); ri = Ref{Cfloat}()
-    chk(ccall((:wl_mg_solve, libwlhip), Cint, (Ptr{Cvoid}, Cdouble, Cint, Ref{Cint}, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}), m.handle, tol, itmx, n, r1, ri, C_NULL))
+    chk(ccall((:wl_mg_solve, libwlhip), Cint, (Ptr{Cvoid}, Cdouble, Cint, Ref{Cint}, Ref{Cdouble}, Ref{Cfloat}, Ptr{Cvoid}), m.handle, Cdouble(tol), Cint(itmx), n, r1, ri, C_NULL))
     push!(m.n, n[])
 end
+mult!(m::HipMultiLevel, x::HA) = (l = level(m, 1); perBC!(x, m.perdir);
+    chk(ccall((:wl_mult, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ptr{Cvoid}), m.z.ptr, m.L.ptr, l.D.ptr, x.ptr, sgrid(x), C_NULL)); m.z)   # src/MultiLevelPoisson.jl:103
+L₁(m::HipMultiLevel) = norms(level(m, 1).r)[1]
+L∞(m::HipMultiLevel) = norms(level(m, 1).r)[2]
+
+# wl_sim_desc (include/wlhip.h): the flow's own arrays + the spare velocity buffer
+struct WlSimDesc
+    D::Int32; dims::NTuple{3,Int32}; uBC::NTuple{3,Cfloat}; nu::Cfloat; dt0::Cfloat; perdir_mask::UInt32; exitBC::Int32; scheme::Int32; has_body::Int32
+    u::Ptr{Cfloat}; u0::Ptr{Cfloat}; f::Ptr{Cfloat}; p::Ptr{Cfloat}; sigma::Ptr{Cfloat}; V::Ptr{Cfloat}; mu0::Ptr{Cfloat}; mu1::Ptr{Cfloat}; us::Ptr{Cfloat}
+end
+# flows that went through measure! with a real body: BDIM! needs μ₁ and V there (NoBody: μ₁ ≡ 0, V ≡ 0 are never read)
+const BODIED = WeakKeyDict{Any,Bool}()
+has_body(a::HFlow) = get(BODIED, a.μ₁, false)
+function composite!(a::HFlow{D}, b::HipMultiLevel) where {D}
+    if b.sim != C_NULL && (b.flowkey != objectid(a) || b.has_body != has_body(a))
+        chk(ccall((:wl_sim_destroy, libwlhip), Cint, (Ptr{Cvoid},), b.sim)); b.sim = C_NULL
+    end
+    b.sim != C_NULL && return b.sim
+    @assert b.x === a.p && b.L === a.μ₀ && b.z === a.σ "the composite time step needs the MultiLevelPoisson built on this flow's p, μ₀, σ"
+    uBC = a.uBC isa Tuple ? pad3(a.uBC) : (0f0, 0f0, 0f0)
+    N = size(a.p) .- 2
+    spare = (b.spare === nothing || size(b.spare) != size(a.u)) ? similar(a.u) : b.spare
+    d = Ref(WlSimDesc(D, ntuple(i -> i <= D ? Int32(N[i]) : Int32(1), 3), uBC, a.ν, a.Δt[end], pmask(a.perdir), Int32(a.exitBC), scheme(a.λ), Int32(has_body(a)),
+                      a.u.ptr, a.u⁰.ptr, a.f.ptr, a.p.ptr, a.σ.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, a.exitBC ? Ptr{Cfloat}(C_NULL) : spare.ptr))
+    h = Ref{Ptr{Cvoid}}()
+    chk(ccall((:wl_sim_create_on, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Ref{WlSimDesc}, Ptr{Cvoid}), h, d, b.handle))
+    b.sim = h[]; b.spare = spare; b.flowkey = objectid(a); b.has_body = has_body(a)
+    has_body(a) && chk(ccall((:wl_sim_update, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), b.sim, C_NULL))       # body masks of the BDIM! fast paths
+    b.sim
+end
+simfield(sim, name) = ccall((:wl_sim_field, libwlhip), Ptr{Cfloat}, (Ptr{Cvoid}, Cstring), sim, name)
+# mom_step!(a,b) src/Flow.jl:156-167 as ONE library call: the fused kernels (conv_diff!+BDIM!, div+residual!, blocked smoother,
+# projection+CFL) of wl_sim_mom_step.  Closures (uBC(i,x,t), g(i,x,t), udf) cannot cross the C ABI: such flows take the reference's
+# own mom_step! over the leaf methods above.
+function mom_step!(a::HFlow{D}, b::HipMultiLevel; udf=nothing, kwargs...) where {D}
+    if a.uBC isa Function || a.g !== nothing || udf !== nothing
+        return invoke(mom_step!, Tuple{AbstractFlow,AbstractPoisson}, a, b; udf, kwargs...)
+    end
+    sim = composite!(a, b)
+    chk(ccall((:wl_sim_set_dt_last, libwlhip), Cint, (Ptr{Cvoid}, Cfloat), sim, a.Δt[end]))    # the host owns flow.Δt (src/Flow.jl:127)
+    chk(ccall((:wl_sim_mom_step, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), sim, C_NULL))
+    # the step permuted the roles of {u, u⁰, spare}: re-point the three objects (same buffers, same owners)
+    a.u.ptr = simfield(sim, "u"); a.u⁰.ptr = simfield(sim, "u0")
+    b.spare !== nothing && !a.exitBC && (b.spare.ptr = simfield(sim, "us"))
+    push!(a.Δt, ccall((:wl_sim_dt_last, libwlhip), Cfloat, (Ptr{Cvoid},), sim))                   # push!(a.Δt,CFL(a))
+    hist = Vector{Int16}(undef, length(b.n) + 2)                                                    # pois.n: two solves per step
+    k = ccall((:wl_mg_history, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Int16}, Cint), b.handle, hist, Cint(length(hist)))
+    resize!(hist, k); append!(b.n, hist[length(b.n)+1:end])
+    nothing
+end
+# NOT materialised by the composite (include/wlhip.h "store_f", "store_eps"): flow.f, the interior of flow.σ (z = ∇·u) and
+# pois.levels[1].ϵ after a step — nothing on the time-step path reads them again.  pressure_force below does not use flow.f as scratch.
 
 # temporal averages (src/Metrics.jl:236-252) on device arrays
-function WaterLily.update!(m::WaterLily.MeanFlow{Float32,<:HA}, flow::WaterLily.AbstractFlow)
+function update!(m::WaterLily.MeanFlow{Float32,<:HA}, flow::AbstractFlow)
     dt = WaterLily.time(flow) - m.t[end]
     ε = length(m.t) == 1 ? 1f0 : dt / (dt + WaterLily.time(m) + eps(Float32))
     chk(ccall((:wl_meanflow_update, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ptr{Cvoid}),
-              m.P.ptr, m.U.ptr, m.uu_stats ? m.UU.ptr : C_NULL, flow.p.ptr, flow.u.ptr, sgrid(flow.p), ε, C_NULL))
+              m.P.ptr, m.U.ptr, m.uu_stats ? m.UU.ptr : Ptr{Cfloat}(C_NULL), flow.p.ptr, flow.u.ptr, sgrid(flow.p), Cfloat(ε), C_NULL))
     push!(m.t, m.t[end] + dt)
 end
 
-# ---- closed-form bodies (SURVEY row f1) --------------------------------------------------------------------------
-# An AutoBody holds arbitrary Julia closures, which cannot be shipped to a HIP kernel through a C ABI.  The shapes whose
-# sdf/gradient are known in closed form get their own AbstractBody type; everything else keeps the reference's host path
-# (measure! on Array fields, then copyto! the HipArrays).
+# ---- bodies ---------------------------------------------------------------------------------------------------------------------------
+measure!(::HFlow, ::NoBody; kwargs...) = nothing                 # src/Body.jl:83 (resolves the ambiguity with the generic method below)
+# Any AbstractBody whose `measure` is a Julia closure (AutoBody, SetBody, …): the reference's own measure! (src/Body.jl:28-51) runs on
+# HOST arrays of a shadow flow, the results are uploaded.  O(N) host work per call: meant for static bodies (remeasure=false).
+struct HostShadow{N,T} <: AbstractFlow{N,T}
+    p::Array{T,N}; σ::Array{T,N}; V::Array{T}; μ₀::Array{T}; μ₁::Array{T}; exitBC::Bool; perdir::NTuple
+end
+function measure!(a::HFlow{N}, body::AbstractBody; t=zero(Float32), ϵ=1) where {N}
+    T = Float32
+    sh = HostShadow{N,T}(zeros(T, size(a.p)), zeros(T, size(a.σ)), zeros(T, size(a.V)), ones(T, size(a.μ₀)), zeros(T, size(a.μ₁)), a.exitBC, a.perdir)
+    measure!(sh, body; t, ϵ)                       # the reference's generic method: sh is not an HFlow
+    copyto!(a.σ, sh.σ); copyto!(a.V, sh.V); copyto!(a.μ₀, sh.μ₀); copyto!(a.μ₁, sh.μ₁)
+    BODIED[a.μ₁] = true
+    nothing
+end
+# closed-form shapes on the device (SURVEY row f1)
 struct WlBody; kind::Int32; c::NTuple{3,Cfloat}; R::Cfloat; m::NTuple{3,Cfloat}; V::NTuple{3,Cfloat}; end      # include/wlhip.h wl_body
-pad3(v) = ntuple(i -> i <= length(v) ? Cfloat(v[i]) : 0f0, 3)
 """
     HipBody(:sphere, c, R; V) | HipBody(:cylinder, c, R, axis; V) | HipBody(:plane, point, normal; V)
 
 sdf = |m∘(x−c)|−R (an axis with m=0 is dropped) or m·(x−c).  `c(t)`/`V(t)` may be functions of time: the translating map
 `x − ∫V dt` of the reference's `AutoBody(sdf, map)` (src/AutoBody.jl:36-37).
 """
-struct HipBody{C,VV} <: WaterLily.AbstractBody
+struct HipBody{C,VV} <: AbstractBody
     kind::Int32; c::C; R::Float32; m::NTuple{3,Cfloat}; V::VV
 end
 HipBody(s::Symbol, c, a...; V=(0, 0, 0)) =
@@ -204,22 +378,23 @@ HipBody(s::Symbol, c, a...; V=(0, 0, 0)) =
 at(v::Function, t) = v(t); at(v, t) = v
 wlbody(b::HipBody, D, t) = Ref(WlBody(b.kind, pad3(at(b.c, t)), b.R, ntuple(i -> i <= D ? b.m[i] : 0f0, 3), pad3(at(b.V, t))))
 # measure!(a::Flow,body;t,ϵ)  src/Body.jl:28-51
-function WaterLily.measure!(a::HFlow{D}, body::HipBody; t=zero(Float32), ϵ=1) where D
+function measure!(a::HFlow{D}, body::HipBody; t=zero(Float32), ϵ=1) where {D}
     chk(ccall((:wl_measure_body, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Cfloat, Cint, Cuint, Ptr{Cvoid}),
-              a.σ.ptr, a.μ₀.ptr, a.μ₁.ptr, a.V.ptr, sgrid(a.σ), wlbody(body, D, t), ϵ, a.exitBC, pmask(a.perdir), C_NULL))
+              a.σ.ptr, a.μ₀.ptr, a.μ₁.ptr, a.V.ptr, sgrid(a.σ), wlbody(body, D, t), Cfloat(ϵ), Cint(a.exitBC), pmask(a.perdir), C_NULL))
+    BODIED[a.μ₁] = true
+    nothing
 end
 # pressure_force / viscous_force (src/Metrics.jl:116-133,140-154): Float64 sums on device, flow.f is not used as scratch
-function WaterLily.pressure_force(p::HA, df, body::HipBody, t=0; T=Float64)          # src/Metrics.jl:128
+function WaterLily.pressure_force(p::HA, df::HA, body::HipBody, t=0; T=Float64)          # src/Metrics.jl:128
     out = zeros(Cdouble, 3); D = ndims(p)
     chk(ccall((:wl_pressure_force_body, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), p.ptr, sgrid(p), wlbody(body, D, t), out, C_NULL))
     T.(out[1:D])
 end
-function WaterLily.viscous_force(u::HA, ν, df, body::HipBody, t=0; T=Float64)        # src/Metrics.jl:149
+function WaterLily.viscous_force(u::HA, ν, df::HA, body::HipBody, t=0; T=Float64)        # src/Metrics.jl:149
     out = zeros(Cdouble, 3); D = ndims(u) - 1
-    chk(ccall((:wl_viscous_force_body, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), u.ptr, vgrid(u), ν, wlbody(body, D, t), out, C_NULL))
+    chk(ccall((:wl_viscous_force_body, libwlhip), Cint, (Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), u.ptr, vgrid(u), Cfloat(ν), wlbody(body, D, t), out, C_NULL))
     T.(out[1:D])
 end
-
 function WaterLily.pressure_moment(x₀, p::HA, df, body::HipBody, t=0)                                       # src/Metrics.jl:169
     out = zeros(Cdouble, 3); D = ndims(p)
     chk(ccall((:wl_pressure_moment_body, libwlhip), Cint, (Ref{NTuple{3,Cfloat}}, Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), Ref(pad3(x₀)), p.ptr, sgrid(p), wlbody(body, D, t), out, C_NULL))
@@ -227,9 +402,12 @@ function WaterLily.pressure_moment(x₀, p::HA, df, body::HipBody, t=0)         
 end
 function WaterLily.viscous_moment(x₀, u::HA, ν, df, body::HipBody, t=0)                                     # src/Metrics.jl:183
     out = zeros(Cdouble, 3); D = ndims(u) - 1
-    chk(ccall((:wl_viscous_moment_body, libwlhip), Cint, (Ref{NTuple{3,Cfloat}}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), Ref(pad3(x₀)), u.ptr, vgrid(u), ν, wlbody(body, D, t), out, C_NULL))
+    chk(ccall((:wl_viscous_moment_body, libwlhip), Cint, (Ref{NTuple{3,Cfloat}}, Ptr{Cfloat}, Ref{WlGrid}, Cfloat, Ref{WlBody}, Ptr{Cdouble}, Ptr{Cvoid}), Ref(pad3(x₀)), u.ptr, vgrid(u), Cfloat(ν), wlbody(body, D, t), out, C_NULL))
     out[1:D]
 end
+# closure bodies: the reference's metric on host copies (df is scratch there, src/Metrics.jl:127-131)
+WaterLily.pressure_force(p::HA, df::HA, body::AbstractBody, t=0) = WaterLily.pressure_force(Array(p), Array(df), body, t)
+WaterLily.viscous_force(u::HA, ν, df::HA, body::AbstractBody, t=0) = WaterLily.viscous_force(Array(u), ν, Array(df), body, t)
 
 export HipArray, HipMultiLevel, HipBody
 end # module
