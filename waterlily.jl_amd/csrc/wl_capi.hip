@@ -218,7 +218,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
       { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s)); }
       {   // one RCCL group for both arrays: one exchange latency instead of two
         const bool grp = comm && comm->size > 1 && p.dist;
-        if (grp) WL_TRY(comm->group_begin());
+        if (grp) { WL_TRY(comm->group_begin()); comm->n_halo++; }   // one network round for both arrays
         int rc = halo(p, p.em, 1, s, 3);
         if (rc == 0) rc = halo(p, p.rs, 1, s, 2);
         if (grp) { const int rc2 = comm->group_end(); if (rc == 0) rc = rc2; }

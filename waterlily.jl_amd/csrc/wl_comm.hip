@@ -70,8 +70,8 @@ struct RcclComm : wl_comm {
   ncclComm_t comm = nullptr, comm_async = nullptr;
   int depth = 0;
   ~RcclComm() override { if (comm_async) (void)rccl().CommDestroy(comm_async); if (comm) (void)rccl().CommDestroy(comm); }
-  int group_begin() override { if (depth++ == 0) WL_NCCL(rccl().GroupStart()); return 0; }
-  int group_end() override { if (depth > 0 && --depth == 0) WL_NCCL(rccl().GroupEnd()); return 0; }
+  int group_begin() override { gdepth++; if (depth++ == 0) WL_NCCL(rccl().GroupStart()); return 0; }
+  int group_end() override { if (gdepth > 0) gdepth--; if (depth > 0 && --depth == 0) WL_NCCL(rccl().GroupEnd()); return 0; }
   int sendrecv_body(ncclComm_t cm, const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) {
     // neighbours: lo = rank-1, hi = rank+1 (loopback: both are this rank — what it sends down comes back as its upper ghost planes and
     // vice versa, the z-periodic wrap; sends and receives to one peer match in issue order, hence lo-send / hi-recv first)
@@ -122,7 +122,8 @@ int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t
   const bool has_lo = c->loopback || (g.gk + g.k0 > 1), has_hi = c->loopback || (g.gk + g.k1 < g.gnz - 1);
   const size_t bytes = (size_t)depth * (size_t)g.sz * sizeof(float);
   if (g.k1 - g.k0 < depth || g.k0 < depth) { wl_set_error("halo deeper than the slab"); return WL_EINVAL; }
-  c->n_halo++; c->halo_bytes += (long)bytes * ncomp * ((has_lo ? 1 : 0) + (has_hi ? 1 : 0));
+  if (c->gdepth == 0) c->n_halo++;     // an exchange inside an open group belongs to the round that opened it
+  c->halo_bytes += (long)bytes * ncomp * ((has_lo ? 1 : 0) + (has_hi ? 1 : 0));
   WL_TRY(c->group_begin());
   for (int q = 0; q < ncomp; q++) {
     float* b = a + (size_t)q * g.cs;

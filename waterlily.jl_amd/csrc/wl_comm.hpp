@@ -10,8 +10,10 @@ struct wl_comm {
   // lo neighbour = rank-1, hi neighbour = rank+1; pointers are NULL where there is no neighbour
   virtual int sendrecv(const void* send_lo, void* recv_lo, const void* send_hi, void* recv_hi, size_t bytes, hipStream_t s) = 0;
   virtual int allgather(const void* send, void* recv, size_t bytes_each, hipStream_t s) = 0;
-  virtual int group_begin() { return 0; }
-  virtual int group_end() { return 0; }
+  // exchanges issued between group_begin and group_end form ONE network round (RCCL: one ncclGroup); n_halo counts rounds
+  int gdepth = 0;
+  virtual int group_begin() { gdepth++; return 0; }
+  virtual int group_end() { if (gdepth > 0) gdepth--; return 0; }
   int ensure_scratch();
   // counters since creation (wl_comm_stats): halo exchanges, bytes this rank sent in them, scalar combines, plane all-gathers
   long n_halo = 0, halo_bytes = 0, n_combine = 0, n_gather = 0;

@@ -43,8 +43,11 @@ bool gsrb_pair_geom_ok(const GridX& g) {
 }
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl) { return cl.on && gsrb_pair_geom_ok(g); }
 // 16-row tiles where the 32-row tiling cannot fill the chip for many rounds (WL_PAIR_ROWS=16|32 forces one: experiments)
-static bool rows16(const GridX& g) {
-  static const int force = getenv("WL_PAIR_ROWS") ? atoi(getenv("WL_PAIR_ROWS")) : 0;
+static bool rows16(const GridX& g, int kernel = 0) {   // kernel: 1 = A, 2 = B (experiments: WL_PAIR_ROWS_A / WL_PAIR_ROWS_B force one kernel's tile height)
+  static const int force_all = getenv("WL_PAIR_ROWS") ? atoi(getenv("WL_PAIR_ROWS")) : 0;
+  static const int force_a = getenv("WL_PAIR_ROWS_A") ? atoi(getenv("WL_PAIR_ROWS_A")) : 0;
+  static const int force_b = getenv("WL_PAIR_ROWS_B") ? atoi(getenv("WL_PAIR_ROWS_B")) : 0;
+  const int force = (kernel == 1 && force_a) ? force_a : ((kernel == 2 && force_b) ? force_b : force_all);
   if (force == 16) return true;
   if (force == 32) return false;
   // measured: 256³ levels gain (A+B 0.28 -> 0.24 ms), 512³ loses (B 0.72 -> 0.80 ms), 128³ and below lose slightly
@@ -54,13 +57,13 @@ static bool rows16(const GridX& g) {
   return tiles32 >= 24 && tiles32 < 128 && rounds32 >= 128 && rounds32 < 2048;
 }
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s) {
-  return rows16(g) ? pair16::gsrb_pair_A(emid, r, g, cl, s) : pair32::gsrb_pair_A(emid, r, g, cl, s);
+  return rows16(g, 1) ? pair16::gsrb_pair_A(emid, r, g, cl, s) : pair32::gsrb_pair_A(emid, r, g, cl, s);
 }
 int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s) {
-  return rows16(g) ? pair16::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s) : pair32::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s);
+  return rows16(g, 1) ? pair16::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s) : pair32::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s);
 }
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {
-  return rows16(g) ? pair16::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s) : pair32::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s);
+  return rows16(g, 2) ? pair16::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s) : pair32::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s);
 }
 }  // namespace wl
