@@ -1,6 +1,7 @@
 """Solver- and step-level parity of the HIP path (through the C ABI) against the oracle, including the
 reference's own known-answer tests re-run on the GPU path (file:line given per test)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -840,3 +841,35 @@ def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
     # the corrector's input went through a pressure solve (reductions): the two HIP paths must still agree exactly
     assert np.array_equal(res[1][1], res[0][1]), "tiled vs plane kernel (corrector)"
     assert np.abs(res[1][1] - outo[1]).max() < 2e-5
+
+
+@pytest.mark.parametrize("dims", [(64, 32, 24), (96, 64, 40), (70, 44, 18), (128, 36, 12)])
+def test_fused_projection_head_is_bit_identical(w, oracle, dims):
+    """mom_project!'s head (z=∇·u, x·=dt, residual!) and the V-cycle's first Jacobi! in ONE z-marching kernel (wl_resjac.hip), assuming
+    the mean shift of residual! is not due — against the two-kernel path bit for bit and against the oracle (u, p, pois.n, Δt), on whole
+    and ragged tiles and several z-chunks; and the redo path (shift declared due: results discarded, two-kernel path taken)."""
+    rng = np.random.default_rng(53)
+    Ng = tuple(n + 2 for n in dims)
+    u_init = np.asfortranarray(rng.uniform(-0.4, 0.4, size=Ng + (3,)).astype(np.float32))
+    u_init[..., 0] += 1.0
+    so = oracle.Simulation(dims, (1.0, 0.0, 0.0), dims[0], U=1, nu=0.02, T=np.float32)
+    oracle.BC(u_init, (1.0, 0.0, 0.0))
+    so.field("u")[...] = u_init
+    so.field("u0")[...] = u_init
+    res = {}
+    for mode in (1, 0, 2):
+        sg = w.FusedSimulation(dims, (1.0, 0.0, 0.0), dims[0], U=1, nu=0.02, u0=u_init)
+        sg.set_option("resjac_min", 0)
+        sg.set_option("resjac", mode)
+        os.environ.pop("WL_RJ_CHUNK", None)
+        for _ in range(3):
+            sg.mom_step_()
+        res[mode] = (sg.field("u"), sg.field("p"), sg.pois_n, sg.dt)
+        sg.set_option("resjac_min", 8 << 20)
+    for _ in range(3):
+        so.step(remeasure=False)
+    for mode in (1, 2):
+        assert res[mode][2] == res[0][2] and res[mode][3] == res[0][3], mode
+        assert np.array_equal(res[mode][0], res[0][0]) and np.array_equal(res[mode][1], res[0][1]), mode
+    assert res[1][2] == so.pois_n
+    assert np.abs(res[1][0] - so.u).max() < 5e-5 and np.abs(res[1][1] - so.p).max() < 5e-4

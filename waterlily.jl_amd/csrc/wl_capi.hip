@@ -271,7 +271,8 @@ int wl_mg::tail(int first, float w, hipStream_t s) {
 int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                            // Vcycle! :88-101
   Level& fine = lv[(size_t)l]; Level& coarse = lv[(size_t)l + 1];
   // Jacobi!(fine): ϵ=r·iD; increment!(ω=1)   (perBC!(ϵ) inside increment!)
-  {
+  if (l == 0 && jacobi0_done) jacobi0_done = false;   // Jacobi!(fine) was fused into the projection head (wl_sim::project → wl::resjac)
+  else {
     ProfScope pj(l == 0 ? WL_PROF_JACOBI : -1, s);
     if (!perdir && (!fine.dist || fine.cl.on)) {   // one pass; new residual lands in the ϵ buffer, then the two buffers trade places
       WL_TRY(halo(fine, fine.r, 1, s));              // (slab: ϵ=r·iD of the neighbour's boundary plane is recomputed from its r; iD is evaluated from the position)
@@ -333,8 +334,8 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     WL_TRY(wl::combine_results(comm, ws, s));
     // mean shift + r₁ -> res_d[1], r∞ -> res_f[0] — unless the V-cycle's first operation is the z-marching Jacobi! on this level
     // (always run: nᵖ ≥ 1): that kernel applies the shift as it loads r and accumulates the norms, no pass over r at all
-    shift_pending = defer_shift && itmx >= 1 && !(comm && comm->size > 1) && !perdir && lv.size() > 1 && wl::jacobi_takes_shift(p.x_, p.cl);
-    if (!shift_pending) WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));
+    shift_pending = !jacobi0_done && defer_shift && itmx >= 1 && !(comm && comm->size > 1) && !perdir && lv.size() > 1 && wl::jacobi_takes_shift(p.x_, p.cl);
+    if (!shift_pending && !jacobi0_done) WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));
   }
   double hd[7]; float hf[4];
   float w = 1.f;

@@ -243,6 +243,10 @@ int mean_shift(float* r, const GridX& g, const RedWs& ws, hipStream_t s);
 int div_residual(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws, const ConstL& cl, hipStream_t s);
 int div_residual_split(float* z, float* xout, float* r, const float* x, const float* u, const float* L, const float* D, const float* iD, const GridX& g, float dt, const RedWs& ws,
                        const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);
+// fused head of mom_project! + the V-cycle's first Jacobi! on the finest level (wl_resjac.hip)
+void resjac_enable(int on, long min_cells);
+bool resjac_ok(const GridX& g, const ConstL& cl);
+int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s);
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s);
 int project_unscale_split(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);

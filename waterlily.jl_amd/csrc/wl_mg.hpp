@@ -30,6 +30,7 @@ struct wl_mg {
   bool skip_fill = true;    // Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi! (x = ω·ϵ instead of x += ω·ϵ)
   bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
   bool shift_pending = false;
+  bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
   bool tail_ok(int first) const;

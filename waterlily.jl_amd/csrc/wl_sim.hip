@@ -406,6 +406,9 @@ struct wl_sim {
     WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
+  bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
+  bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
+  long n_resjac = 0, n_resjac_redo = 0;   // how often the fused head stood / had to be redone because the mean shift was due
   bool use_fuse_cfl = true;  // the corrector's projection tail also produces CFL's σ and max(σ)
   bool cfl_done = false;
   int project(float w, hipStream_t s, bool with_cfl = false) {                           // mom_project! :223-232
@@ -416,14 +419,27 @@ struct wl_sim {
       WL_TRY(wl::bc_per_scalar(p, G, d.perdir_mask, s));                                   // residual!: perBC!(x) :93 (copies commute with the scaling)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
-      {
+      bool head_done = false;
+      if (use_resjac && !store_f && !comm && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl)) {
+        // head + the V-cycle's first Jacobi!(fine) in one launch, assuming residual!'s mean shift is not due (wl_resjac.hip); Σr decides
+        { ProfScope pr(WL_PROF_RESIDUAL, s);
+          WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s)); }
+        double sr; WL_TRY(wl::read_results(mg->ws, &sr, 1, nullptr, 0, s));
+        const float sm = (float)sr / (float)(double)wl_ninside_global(mg->lv[0].g);
+        if (std::fabs(sm) <= 2.f * 1.1920929e-7f && !resjac_force_redo) {                                       // src/Poisson.jl:96: no shift — the fused results stand
+          std::swap(p, ps); l0.x = p;
+          std::swap(l0.r, l0.eps);
+          mg->jacobi0_done = true; head_done = true; n_resjac++;
+        } else n_resjac_redo++;                                                            // shift due: the inputs are untouched, take the two-kernel path
+      }
+      if (!head_done) {
         ProfScope pr(WL_PROF_RESIDUAL, s);
         if (l0.part && mg->use_zsplit && !comm) {   // a body: coefficients from the position on the plane ranges away from it (as in smooth!)
           const int m = 4, na = std::max(l0.g.k0, l0.za - m), nb = std::min(l0.g.k1, l0.zb + m + 1);
           WL_TRY(wl::div_residual_split(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, l0.clp, na, nb, s));
         } else WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s));
       }
-      std::swap(p, ps); l0.x = p;
+      if (!head_done) { std::swap(p, ps); l0.x = p; }
       WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
       const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
@@ -616,6 +632,8 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "jacobi_march") { wl::jacobi_march_enable(value); return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
+  if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
+  if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
   if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
