@@ -167,7 +167,7 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
 // (non-periodic, no exitBC).  Cells outside the interior of u_out are left for BC! to write.
 template <int D, int CL>
 __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout,
-                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1) {
+                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1, int store_sigma) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   float mx = -INFINITY;
@@ -205,7 +205,7 @@ __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __
           uout[2 * g.cs + o] = uzn;
           sg += (fmaxf(0.f, uzp) + fmaxf(0.f, -uzn));
         }
-        sigma[o] = sg;
+        if (store_sigma) sigma[o] = sg;       // σ = flux_out is only read by the maximum taken here: materialised on request
       } else sg = sigma[o];
       if (k >= kfirst && k < klast) mx = fmaxf(mx, sg);
       xkm = xc; xc = xkp;
@@ -790,18 +790,18 @@ int project_unscale_split(float* u, const float* L, const float* x, float* pout,
   WL_LAUNCH_CHECK(); return 0;
 }
 // projection tail + CFL's σ and max(σ) -> ws.res_f[slot_f]; u_out must not alias u_in
-int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s) {
+int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma) {
   if (uout == uin) { wl_set_error("project_cfl: output aliases input"); return WL_EINVAL; }
   int kfirst = 0, klast = 1;
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   const int zc = wl_march_chunk(g, g.nz);
   const dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
-  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz);
+  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz, store_sigma);
   hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 int project_cfl_split(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& near, const ConstL& far,
-                      int na, int nb, const RedWs& ws, int slot_f, hipStream_t s) {
+                      int na, int nb, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma) {
   if (uout == uin) { wl_set_error("project_cfl: output aliases input"); return WL_EINVAL; }
   int kfirst = 0, klast = 1;
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
@@ -814,7 +814,7 @@ int project_cfl_split(float* uout, const float* uin, const float* L, const float
     const int zc = wl_march_chunk(g, np);
     const dim3 grid = wl_plane_grid(g, wl_march_slots(np, zc));
     if (off + (int)grid.x > WL_MAXPART) { wl_set_error("project_cfl_split: too many partial maxima"); return WL_EINVAL; }
-    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q]);
+    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q], store_sigma);
     off += (int)grid.x;
   }
   hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, off, ws.res_f + slot_f);

@@ -445,8 +445,8 @@ struct wl_sim {
       const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
       const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
       if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
-        if (split) WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s));
-        else WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s));
+        if (split) WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s, store_f ? 1 : 0));
+        else WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s, store_f ? 1 : 0));
         WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
         std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
       } else if (split) WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s));
