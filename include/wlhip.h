@@ -190,6 +190,8 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    "defer_shift"[1] residual!'s mean shift + solver!'s first norms folded into the finest level's z-marching Jacobi!
    "skip_fill"[1] Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi!
    "convt"[1] LDS-tiled z-marching conv_diff!+BDIM! (NoBody, no periodic direction, f not stored; v > 1: on with z-chunks of v planes)
+   "bcfold"[1] BC!(u,U) for a tuple U folded into the stores of the kernels that produce u (single domain, no exit, no periodic direction):
+   bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[8 Mi cells] size gate (tests: 0)
    "convt_min"[8192] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0) */

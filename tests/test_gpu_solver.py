@@ -873,3 +873,37 @@ def test_fused_projection_head_is_bit_identical(w, oracle, dims):
         assert np.array_equal(res[mode][0], res[0][0]) and np.array_equal(res[mode][1], res[0][1]), mode
     assert res[1][2] == so.pois_n
     assert np.abs(res[1][0] - so.u).max() < 5e-5 and np.abs(res[1][1] - so.p).max() < 5e-4
+
+
+@pytest.mark.parametrize("dims", [(64, 32, 24), (72, 40, 16), (130, 34, 16), (16, 16, 16)])
+@pytest.mark.parametrize("uBC", [(1.0, 0.0, 0.0), (0.3, -0.2, 0.1)])
+def test_bc_folded_into_producers_is_bit_identical(w, oracle, dims, uBC):
+    """BC!(u,U) for a tuple U folded into the stores of the kernels that produce u (tiled conv_diff!+BDIM!: x/y in the wall tiles + one
+    z-plane launch; projection tails: every boundary-adjacent cell also writes the ghost locations it owns) — against the separate
+    k_bc_vec launches bit for bit on EVERY cell (ghosts, edges, corners), and against the oracle."""
+    rng = np.random.default_rng(59)
+    Ng = tuple(n + 2 for n in dims)
+    u_init = np.asfortranarray(rng.uniform(-0.4, 0.4, size=Ng + (3,)).astype(np.float32))
+    so = oracle.Simulation(dims, uBC, dims[0], U=1, nu=0.02, T=np.float32)
+    oracle.BC(u_init, uBC)
+    so.field("u")[...] = u_init
+    so.field("u0")[...] = u_init
+    res = {}
+    for fold in (3, 1, 0):
+        sg = w.FusedSimulation(dims, uBC, dims[0], U=1, nu=0.02, u0=u_init)
+        sg.set_option("bcfold", fold)      # bit 0: projection tails, bit 1: tiled conv_diff!+BDIM!
+        sg.set_option("convt_min", 0)
+        sg.set_option("resjac_min", 0)
+        for _ in range(3):
+            sg.mom_step_()
+        res[fold] = (sg.field("u"), sg.field("u0"), sg.field("p"), sg.pois_n, sg.dt)
+        sg.set_option("convt_min", 8192)
+        sg.set_option("resjac_min", 8 << 20)
+    for _ in range(3):
+        so.step(remeasure=False)
+    for fold in (3, 1):
+        assert res[fold][3] == res[0][3] and res[fold][4] == res[0][4]
+        for q in range(3):
+            assert np.array_equal(res[fold][q], res[0][q]), (fold, ("u", "u0", "p")[q])
+    assert res[3][3] == so.pois_n
+    assert np.abs(res[3][0] - so.u).max() < 5e-5

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -171,6 +172,9 @@ struct ProfScope {   // RAII: records start at construction and stop at destruct
   ~ProfScope();
 };
 
+// BC!(u,U) for a tuple U folded into a producer's stores (wl_bcfold.hpp): request (on = 1, U) / report (on = 1 if it was applied)
+struct BcFold { int on; float U[3]; };
+
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {
 // A level whose face coefficients are verified (on device, exact comparison) to be "c[a] inside, 0 on the wall faces":
@@ -194,12 +198,13 @@ int l1_linf_dev(const float* a, size_t n, const RedWs& ws, int slot_d, int slot_
 int max_dev(const float* a, size_t n, const RedWs& ws, int slot_f, hipStream_t s);
 int dot_dev(const float* a, const float* b, size_t n, const RedWs& ws, int slot, hipStream_t s);
 int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s);
+std::mutex& wl_read_mutex();   // guards the process-wide pinned staging scalars of WlCtx
 
 int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per, hipStream_t s);
 int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s);
 int conv_diff(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                   float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka = -(1 << 30), int kb = 1 << 30, bool q1 = true);   // [ka,kb): plane sub-range; q1: also the Φ ghost pass
+                   float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka = -(1 << 30), int kb = 1 << 30, bool q1 = true, BcFold* fold = nullptr);   // [ka,kb): plane sub-range; q1: also the Φ ghost pass; fold: BC!(u_out,U) folded into the stores where possible (in/out)
 int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s);
 bool conv_z_ok(const GridX& g, unsigned per);
 int conv_diff_z(float* f, const float* u_adv, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, int scheme, float dt, float pre, float post, hipStream_t s);
@@ -210,6 +215,7 @@ int add_field(float* r, const float* gfield, size_t n, hipStream_t s);
 int meanflow_update(float* P, float* U, float* UU, const float* p, const float* u, const GridX& g, float e, hipStream_t s);
 int meanflow_uu(float* tau, const float* UU, const float* U, const GridX& g, hipStream_t s);
 // z-marching LDS-tiled conv_diff!+BDIM! (wl_convt.hip): the default fused path on grids that fill the chip
+int bc_zplanes(float* u, const GridX& g, float U2, hipStream_t s);
 void conv_tile_enable(int on, int chunk);
 void conv_tile_min(long tile_planes);
 bool conv_tile_ok(const GridX& g, unsigned per, int nplanes);
@@ -247,8 +253,8 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
 void resjac_enable(int on, long min_cells);
 bool resjac_ok(const GridX& g, const ConstL& cl);
 int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
-int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s);
-int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma = 1);
+int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold = nullptr);
+int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma = 1, const BcFold* fold = nullptr);
 int project_unscale_split(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);
 int project_cfl_split(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& near, const ConstL& far,
                       int na, int nb, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma = 1);

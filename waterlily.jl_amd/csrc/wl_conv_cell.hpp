@@ -137,7 +137,8 @@ __device__ __forceinline__ void cd_cell(const GridX& g, const float* __restrict_
 struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre, post; int scale_after; int cl_on; float cl_c[3];
                   // FUSE == 2 (flows with a body): per workgroup and plane, 1 = the body is near (μ₁ or V nonzero) / 1 = a near cell reads f here
                   const unsigned char* near; const unsigned char* needf; int nbm; int store_all;
-                  const unsigned char* m0var; };   // m0var: 1 = μ₀ deviates from "1 inside, 0 on wall faces" somewhere in the workgroup's cells
+                  const unsigned char* m0var;      // m0var: 1 = μ₀ deviates from "1 inside, 0 on wall faces" somewhere in the workgroup's cells
+                  int bc_on; float bcU[3]; };      // BC!(u_out, U) folded into the stores (wl_bcfold.hpp): only the tiled kernel honours it
 // FUSE epilogue shared by both kernels: f = u⁰ + Δt·r (all cells) ; u_out = (u·pre + μ₀·f)·post (interior)      BDIM! NoBody, src/Flow.jl:176-180
 template <int D, typename IDX>
 __device__ __forceinline__ void cd_store(const GridX& g, float* __restrict__ r, const float* __restrict__ u, IDX o, const int* I, const int* N, bool in, const float* out, int fuse, const BdimArgs& bd) {

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <type_traits>
 
+#include "wl_bcfold.hpp"
 #include "wl_conv_cell.hpp"
 
 namespace {
@@ -189,8 +190,15 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
   // The results of plane k are stored at the top of iteration k+1, AFTER that iteration's loads have been issued: every wait on
   // the vector-memory counter (in order, loads and stores alike) then only ever covers operations issued a whole plane earlier.
   float2 un[3];
-  auto store_plane = [&](int kq) {
+  auto store_plane = [&](auto wtag, int kq) {
     const unsigned kqo = (unsigned)kq * sz;
+    if (decltype(wtag)::value && SCH != WL_VANLEER && bd.bc_on && (x <= 1 || x + 1 >= g.nx - 2 || y <= 1 || y >= g.ny - 2)) {   // (vanLeer: no registers to spare — BC! stays a launch)
+      // threads on an x/y wall: BC!(u_out, U) in x and y folded into the stores (wl_bcfold.hpp) — cells on a Dirichlet face take U, cells
+      // next to a ghost column/row also fill it; the z ghost planes are completed by k_bc_zplanes after the launch
+      if (in0) { const float v[3] = {un[0].x, un[1].x, un[2].x}; wl_bc_fold_store_xy(bd.uout, g, x, y, kq, v, bd.bcU); }
+      if (in1) { const float v[3] = {un[0].y, un[1].y, un[2].y}; wl_bc_fold_store_xy(bd.uout, g, x + 1, y, kq, v, bd.bcU); }
+      return;
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
       const unsigned oa = (unsigned)a * cs + kqo + pc.off;
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
 #pragma unroll
         for (int a = 0; a < 3; a++) { u0v[a] = ldg2(bd.u0, (unsigned)a * cs + ko + pc.off); if (!FULL) u0v[a] = pair_fix(u0v[a], pc.mode); }
       }
-      if (k > ks) store_plane(k - 1);
+      if (k > ks) store_plane(wtag, k - 1);
       const float* Pm = lds + ((k - 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
       const float* P0 = lds + (k & (CT_NSLOT - 1)) * CT_SLOT + my;
       const float* Pp = lds + ((k + 1) & (CT_NSLOT - 1)) * CT_SLOT + my;
@@ -295,13 +303,29 @@ __global__ void __launch_bounds__(CT_N, 4) k_conv_tile(GridX g, const float* __r
       }
       __syncthreads();     // plane k+2 is visible to the next iteration; nobody still reads the slot the next iteration overwrites
     }
+    store_plane(wtag, ke - 1);
   };
   if (tile_walls) mainloop(std::integral_constant<int, 1>{}); else mainloop(std::integral_constant<int, 0>{});
-  store_plane(ke - 1);
+}
+// completes BC!(u,U) after a producer that folded the x/y part into its stores: plane 0 ← plane 1 and plane nz−1 ← plane nz−2 for the
+// tangential components (whole planes, ghost rows and columns included: they were filled by the wall tiles), U for the normal component
+// on planes 0, 1 and nz−1 (Julia indices 1, 2, N)       src/core.jl:200-219
+__global__ void k_bc_zplanes(GridX g, float* __restrict__ u, float U2) {
+  const long sz = g.sz, cs = g.cs;
+  for (long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x; m < sz; m += (long)gridDim.x * WL_BLOCK) {
+    const long top = (long)(g.nz - 1) * sz;
+    u[m] = u[sz + m]; u[cs + m] = u[cs + sz + m];                                  // plane 0: x and y components of plane 1
+    u[top + m] = u[top - sz + m]; u[cs + top + m] = u[cs + top - sz + m];          // plane nz−1: those of plane nz−2
+    u[2 * cs + m] = U2; u[2 * cs + sz + m] = U2; u[2 * cs + top + m] = U2;         // normal component: U on planes 0, 1, nz−1
+  }
 }
 }  // namespace
 
 namespace wl {
+int bc_zplanes(float* u, const GridX& g, float U2, hipStream_t s) {
+  hipLaunchKernelGGL(k_bc_zplanes, dim3(256), dim3(WL_BLOCK), 0, s, g, u, U2);
+  WL_LAUNCH_CHECK(); return 0;
+}
 void conv_tile_enable(int on, int chunk) { g_convt_on = on; g_convt_chunk = chunk; }
 void conv_tile_min(long tile_planes) { g_convt_min = tile_planes; }
 // geometry the tiled kernel pays for: 3-D, 32-bit offsets over the three components, enough tile-planes to fill the chip

@@ -2,9 +2,11 @@
 // generic array ops.  Reference semantics: /root/reference/src/Flow.jl, src/core.jl (file:line per kernel).
 // Arithmetic order follows the reference statement by statement (-ffp-contract=off).
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "wl_common.hpp"
+#include "wl_bcfold.hpp"
 #include "wl_conv_cell.hpp"
 
 namespace {
@@ -585,7 +587,10 @@ int dot_dev(const float* a, const float* b, size_t n, const RedWs& ws, int slot,
   hipLaunchKernelGGL(k_fin_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, (int)nb, ws.res_d + slot);
   WL_LAUNCH_CHECK(); return 0;
 }
+// The pinned staging scalars are process-wide: one reader at a time (handles driven from different host threads / streams serialise here)
+std::mutex& wl_read_mutex() { static std::mutex m; return m; }
 int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s) {
+  std::lock_guard<std::mutex> lock(wl_read_mutex());
   WlCtx& c = wl_ctx();
   if (nd > 0) WL_HIP(hipMemcpyAsync(c.h_d, ws.res_d, sizeof(double) * (size_t)nd, hipMemcpyDeviceToHost, s));
   if (nf > 0) WL_HIP(hipMemcpyAsync(c.h_f, ws.res_f, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost, s));
@@ -641,7 +646,7 @@ int bc_per_scalar(float* a, const GridX& g, unsigned per, hipStream_t s) {
 }
 
 template <int D, int SCH>
-static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s, const BdimArgs* bd, int ka, int kb, bool q1) {
+static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, hipStream_t s, const BdimArgs* bd, int ka, int kb, bool q1, BcFold* fold) {
   // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes), cut to [ka,kb)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
@@ -664,7 +669,17 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   // fused NoBody conv_diff!+BDIM! without the f store: the LDS-tiled z-marching kernel (wl_convt.hip) on the owned interior planes
   const int own_a = kfirst > g.k0 ? kfirst : g.k0, own_b = klast < g.k1 ? klast : g.k1;
   const bool tiled = D == 3 && bd && !bd->near && !r && bd->cl_on && wl::conv_tile_ok(g, per, own_b - own_a);
-  if (tiled) WL_TRY(wl::conv_tile(u, g, nu, SCH, own_a, own_b, bd, s));
+  if (tiled) {
+    // BC!(u_out,U) folded into the producer (wl_bcfold.hpp) when this launch covers the whole single domain: x/y in the wall tiles'
+    // stores, the z ghost planes by one small launch — the caller then skips k_bc_vec (fold->on reports what happened)
+    BdimArgs bt = *bd;
+    const bool foldok = fold && fold->on && SCH != WL_VANLEER && g.nz == g.gnz && own_a == g.k0 && own_b == g.k1 && g.nx >= 6 && g.ny >= 6 && g.nz >= 6;
+    bt.bc_on = foldok ? 1 : 0;
+    if (foldok) for (int c = 0; c < 3; c++) bt.bcU[c] = fold->U[c];
+    WL_TRY(wl::conv_tile(u, g, nu, SCH, own_a, own_b, &bt, s));
+    if (foldok) WL_TRY(wl::bc_zplanes(bt.uout, g, fold->U[2], s));
+    if (fold) fold->on = foldok ? 1 : 0;
+  } else if (fold) fold->on = 0;
   const bool march = !tiled && D == 3 && wl::conv_march_ok(g);   // z-marching variant (wl_convm.hip): same arithmetic, the z-star in registers
   if (march && !(bd && bd->near)) WL_TRY(wl::conv_march(r, u, g, nu, per, SCH, kfirst, klast, bd, s));
 #define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \
@@ -684,11 +699,12 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
 }
 template <int D>
 static int conv_diff_launch(float* r, const float* u, float* Phi, const GridX& g, float nu, unsigned per, int scheme, hipStream_t s, const BdimArgs* bd,
-                            int ka = -(1 << 30), int kb = 1 << 30, bool q1 = true) {
+                            int ka = -(1 << 30), int kb = 1 << 30, bool q1 = true, BcFold* fold = nullptr) {
+  if (fold && g.D != 3) fold->on = 0;
   switch (scheme) {
-    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1);
-    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1);
-    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1);
+    case WL_QUICK: return conv_diff_launch2<D, WL_QUICK>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1, fold);
+    case WL_VANLEER: return conv_diff_launch2<D, WL_VANLEER>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1, fold);
+    case WL_CDS: return conv_diff_launch2<D, WL_CDS>(r, u, Phi, g, nu, per, s, bd, ka, kb, q1, fold);
   }
   wl_set_error("unknown scheme"); return WL_EINVAL;
 }
@@ -710,10 +726,11 @@ int conv_q1(float* Phi, const float* u, const GridX& g, float nu, unsigned per, 
 }
 // conv_diff!(f,u_adv,σ) + BDIM! (NoBody) in one launch: u_out (and f unless f == NULL) written, u_out must not alias u_adv
 int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                   float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka, int kb, bool q1) {
+                   float dt, float pre, float post, const ConstL& cl, hipStream_t s, int ka, int kb, bool q1, BcFold* fold) {
   if (u_out == u_adv) { wl_set_error("conv_diff_bdim: output aliases the advecting field"); return WL_EINVAL; }
   BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, cl.on, {cl.c[0], cl.c[1], cl.c[2]}};
-  return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd, ka, kb, q1) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
+  if (g.D != 3) { if (fold) fold->on = 0; return conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd); }
+  return conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd, ka, kb, q1, fold);
 }
 // conv_diff!+BDIM! for a flow with a body (see k_conv_diff<…,FUSE=2>): u_out ≠ u_adv; f is an output array (raw r near the body)
 int conv_diff_bdim_body(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "wl_common.hpp"
+#include "wl_bcfold.hpp"
 
 namespace {
 
@@ -137,7 +138,7 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
 // mom_project! tail (src/Flow.jl:227-230): u[I,i] -= L[I,i]·∂ᵢx ; p_out = x/dt (ALL cells), p_out ≠ x
 template <int D, int CL>
 __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl, int zchunk,
-                                  int p0, int p1) {   // local planes [p0,p1) of this launch
+                                  int p0, int p1, BcFold bc) {   // local planes [p0,p1) of this launch; bc.on: BC!(u,U) folded into the stores (wl_bcfold.hpp)
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
@@ -153,9 +154,16 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
     if (D == 3) in = in && k >= g.k0 && k < g.k1;
     if (in) {
       const float lx = CL ? lxc : L[o], ly = CL ? lyc : L[g.cs + o];
+      if (D == 3 && bc.on) {
+        const float lz = CL ? wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]) : L[2 * g.cs + o];
+        const float v[3] = {u[o] - lx * (xc - x[o - 1]), u[g.cs + o] - ly * (xc - x[o - g.sy]), u[2 * g.cs + o] - lz * (xc - xkm)};
+        if (wl_bc_fold_plain(g, i, j, k)) { u[o] = v[0]; u[g.cs + o] = v[1]; u[2 * g.cs + o] = v[2]; }
+        else wl_bc_fold_store(u, g, i, j, k, v, bc.U);
+      } else {
       u[o] -= lx * (xc - x[o - 1]);
       u[g.cs + o] -= ly * (xc - x[o - g.sy]);
       if (D == 3) { const float lz = CL ? wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]) : L[2 * g.cs + o]; u[2 * g.cs + o] -= lz * (xc - xkm); }
+      }
     }
     xkm = xc;
   }
@@ -167,7 +175,7 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
 // (non-periodic, no exitBC).  Cells outside the interior of u_out are left for BC! to write.
 template <int D, int CL>
 __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout,
-                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1, int store_sigma) {
+                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1, int store_sigma, BcFold bc) {
   int i, j; long m; int pz;
   wl_tile(g, m, pz);
   float mx = -INFINITY;
@@ -196,13 +204,15 @@ __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __
         }
         const float uxn = uin[o] - lx * (xc - x[o - 1]), uxp = uin[o + 1] - lxp * (x[o + 1] - xc);
         const float uyn = uin[g.cs + o] - ly * (xc - x[o - g.sy]), uyp = uin[g.cs + o + g.sy] - lyp * (x[o + g.sy] - xc);
-        uout[o] = uxn; uout[g.cs + o] = uyn;
+        const bool foldc = D == 3 && bc.on && !wl_bc_fold_plain(g, i, j, k);      // BC!(u_out,U) folded into the stores of the cells near the boundary
+        if (!foldc) { uout[o] = uxn; uout[g.cs + o] = uyn; }
         sg = 0.f;
         sg += (fmaxf(0.f, uxp) + fmaxf(0.f, -uxn));
         sg += (fmaxf(0.f, uyp) + fmaxf(0.f, -uyn));
         if (D == 3) {
           const float uzn = uin[2 * g.cs + o] - lz * (xc - xkm), uzp = uin[2 * g.cs + o + g.sz] - lzp * (xkp - xc);
-          uout[2 * g.cs + o] = uzn;
+          if (!foldc) uout[2 * g.cs + o] = uzn;
+          else { const float v[3] = {uxn, uyn, uzn}; wl_bc_fold_store(uout, g, i, j, k, v, bc.U); }
           sg += (fmaxf(0.f, uzp) + fmaxf(0.f, -uzn));
         }
         if (store_sigma) sigma[o] = sg;       // σ = flux_out is only read by the maximum taken here: materialised on request
@@ -772,9 +782,11 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, off, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
-int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s) {
+int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold) {
   const int zc = wl_march_chunk(g, g.nz);
-  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, 0, g.nz);
+  BcFold bc{0, {0.f, 0.f, 0.f}};
+  if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
+  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, 0, g.nz, bc);
   WL_LAUNCH_CHECK(); return 0;
 }
 // level with a body: planes [0,na) and [nb,nz) with the constant-coefficient pattern `far`, [na,nb) reading L (see div_residual_split)
@@ -785,18 +797,20 @@ int project_unscale_split(float* u, const float* L, const float* x, float* pout,
     if (np <= 0) continue;
     const ConstL& cl = q == 1 ? near : far;
     const int zc = wl_march_chunk(g, np);
-    DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(np, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, lo[q], hi[q]);
+    DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(np, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, lo[q], hi[q], BcFold{0, {0.f, 0.f, 0.f}});
   }
   WL_LAUNCH_CHECK(); return 0;
 }
 // projection tail + CFL's σ and max(σ) -> ws.res_f[slot_f]; u_out must not alias u_in
-int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma) {
+int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma, const BcFold* fold) {
   if (uout == uin) { wl_set_error("project_cfl: output aliases input"); return WL_EINVAL; }
   int kfirst = 0, klast = 1;
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  BcFold bc{0, {0.f, 0.f, 0.f}};
+  if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
   const int zc = wl_march_chunk(g, g.nz);
   const dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
-  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz, store_sigma);
+  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz, store_sigma, bc);
   hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
@@ -814,7 +828,7 @@ int project_cfl_split(float* uout, const float* uin, const float* L, const float
     const int zc = wl_march_chunk(g, np);
     const dim3 grid = wl_plane_grid(g, wl_march_slots(np, zc));
     if (off + (int)grid.x > WL_MAXPART) { wl_set_error("project_cfl_split: too many partial maxima"); return WL_EINVAL; }
-    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q], store_sigma);
+    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q], store_sigma, BcFold{0, {0.f, 0.f, 0.f}});
     off += (int)grid.x;
   }
   hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, off, ws.res_f + slot_f);

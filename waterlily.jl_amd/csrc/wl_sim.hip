@@ -301,8 +301,15 @@ struct wl_sim {
   bool use_overlap = true;
   bool u_pending = false;    // an exchange of the array that is now `u` or `u0` is in flight
   int sync_u(hipStream_t s) { if (u_pending) { u_pending = false; return wl::halo_async_wait(comm, s); } return 0; }
+  // BC!(u,U) folded into the stores of the kernel that produced u (wl_bcfold.hpp): single domain, tuple U, no exit, no periodic direction
+  // measured at 512³: projection tails −0.04 ms/step (kept), tiled conv_diff! +0.2…0.4 ms/step — the ghost writes are sector-granular
+  // wherever they happen, and inside the tiled kernel they sit on the wall tiles' critical path (off; `bcfold` = 3 turns it on)
+  int use_bcfold = 1; bool bc_folded = false;    // bit 0: projection tails, bit 1: tiled conv_diff!+BDIM!
+  bool fold_ok(int bit) const { return (use_bcfold & bit) && d.D == 3 && !comm && !d.exitBC && !d.perdir_mask && G.nz == G.gnz && G.nx >= 6 && G.ny >= 6 && G.nz >= 6; }
+  BcFold fold_req(int bit) const { BcFold f{fold_ok(bit) ? 1 : 0, {d.uBC[0], d.uBC[1], d.uBC[2]}}; return f; }
   int bc_u(hipStream_t s) {
     WL_TRY(sync_u(s));
+    if (bc_folded) { bc_folded = false; return 0; }      // the producer already wrote every boundary location
     WL_TRY(wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s));
     if (comm && use_overlap) { WL_TRY(wl::halo_async_begin(comm, u, G, d.D, 2, s)); u_pending = true; return 0; }
     return wl::halo(comm, u, G, d.D, 2, s);
@@ -319,7 +326,10 @@ struct wl_sim {
       return wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k1 - 2, 1 << 30, true);
     }
     WL_TRY(sync_u(s));
-    return wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s);
+    BcFold fr = fold_req(2);
+    WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), 1 << 30, true, &fr));
+    bc_folded = fr.on != 0;
+    return 0;
   }
   bool use_convz = false;    // z-marching conv_diff! (each flux once): bit-identical but measured 6 % SLOWER than the gather kernel at 512³ (opt-in)
   int conv_only(const float* uadv, hipStream_t s) {     // conv_diff!(f,uadv,σ) without BDIM!
@@ -446,11 +456,11 @@ struct wl_sim {
       const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
       if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
         if (split) WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s, store_f ? 1 : 0));
-        else WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s, store_f ? 1 : 0));
+        else { const BcFold fr = fold_req(1); WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s, store_f ? 1 : 0, &fr)); bc_folded = fr.on != 0; }
         WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
         std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
       } else if (split) WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s));
-      else WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s));
+      else { const BcFold fr = fold_req(1); WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s, &fr)); bc_folded = fr.on != 0; }
       std::swap(p, ps); l0.x = p;
       return bc_u(s);
     }
@@ -632,6 +642,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "jacobi_march") { wl::jacobi_march_enable(value); return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
+  if (n == "bcfold") { s->use_bcfold = value; return 0; }   // bit 0: projection tails, bit 1: tiled conv_diff!+BDIM!
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
@@ -715,6 +726,7 @@ static int force_reduce(int which, const float* a, float nu, const GridX& G, con
   hipLaunchKernelGGL(k_fin3, dim3(1), dim3(WL_BLOCK), 0, q, ws.pa, (int)grid.x, ws.res_d + 4);
   WL_LAUNCH_CHECK();
   WL_TRY(wl::combine_results(comm, ws, q));
+  std::lock_guard<std::mutex> lock(wl::wl_read_mutex());
   WlCtx& cx = wl_ctx();
   WL_HIP(hipMemcpyAsync(cx.h_d, ws.res_d + 4, 3 * sizeof(double), hipMemcpyDeviceToHost, q));
   WL_HIP(hipStreamSynchronize(q));
