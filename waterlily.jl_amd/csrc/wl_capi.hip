@@ -214,6 +214,18 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
       p.pend = false;
       // z-slab: the tile pipeline recomputes the neighbour's planes it needs, so the exchanges are r (2 planes) before A and
       // ϵ_mid (3 planes) + r' (2 planes) before B — instead of one exchange per colour sweep
+      if (p.dist && deep_halo && p.g.k0 >= 5 && p.g.k1 - p.g.k0 >= 5) {
+        // z-slab, ONE exchange round per smooth!: r travels 5 planes deep and kernel A also computes r' and ϵ_mid on the 3 (2) ghost planes
+        // kernel B reads, instead of receiving them (x is updated on the owned planes only).  5 planes instead of 2+3+2, one latency
+        // instead of two, ≈6 redundant planes of kernel A per rank.
+        WL_TRY(halo(p, p.r, 1, s, 5));
+        GridX ge = p.x_; ge.k0 = p.x_.k0 - 3; ge.k1 = p.x_.k1 + 3;
+        { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, ge, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1)); }
+        { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
+        norm_slots = 0;
+        if (norms_done) *norms_done = want_norms;
+        return 0;
+      }
       WL_TRY(halo(p, p.r, 1, s, 2));
       { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s)); }
       {   // one RCCL group for both arrays: one exchange latency instead of two
@@ -312,7 +324,7 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
       if (l + 2 < (int)lv.size()) WL_TRY(vcycle(l + 1, w, s, true));                       // its last step may be deferred into the smooth! below
       WL_TRY(smooth(l + 1, 4, w, s));
     }
-    WL_TRY(halo(coarse, coarse.x, 1, s, pair_slab(fine) ? 2 : 1));                         // prolongation reads the coarse cells under my halo planes
+    WL_TRY(halo(coarse, coarse.x, 1, s, pair_slab(fine) ? ((deep_halo && fine.g.k0 >= 5 && fine.g.k1 - fine.g.k0 >= 5 && coarse.g.k0 >= 3 && coarse.g.k1 - coarse.g.k0 >= 3) ? 3 : 2) : 1));   // prolongation reads the coarse cells under my halo planes (deep halo: kernel A starts 5 planes out)
   }
   // prolongate!(fine.ϵ,coarse.x); increment!(fine;ω): the caller's next operation is smooth!(fine;ω) with the same ω — when that
   // smooth! runs as the temporally blocked kernel pair it absorbs this step as an extra pipeline stage (defer).

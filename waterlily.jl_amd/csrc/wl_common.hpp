@@ -277,7 +277,8 @@ int vcycle_tail(const TailLevelHost* lv, int n, float w, hipStream_t s);
 int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* L, const float* Dg, const float* iD, const GridX& g, float a, int more, const RedWs& ws, hipStream_t s);
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s);
-int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s);
+int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
+                     int xk0 = -(1 << 30), int xk1 = 1 << 30);
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
                  const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
 int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStream_t s);
@@ -286,7 +287,8 @@ void gsrb_pair_enable(int on);
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl);
 bool gsrb_pair_geom_ok(const GridX& g);
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s);
-int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s);
+int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
+                    int xk0 = -(1 << 30), int xk1 = 1 << 30);   // [xk0,xk1): planes on which x is updated (default: every output plane)
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
 int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s);

@@ -325,8 +325,9 @@ int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, co
   WL_LAUNCH_CHECK(); return 0;
 }
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
-int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s) {
-  if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s);
+int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
+                     int xk0, int xk1) {
+  if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1);
   if (g.nz != g.gnz) { wl_set_error("blocked smoother on a z-slab level needs the pair kernels"); return WL_EINVAL; }
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;

@@ -39,7 +39,7 @@ namespace wl {
 void gsrb_pair_enable(int on) { g_pair_on = on & 1; g_pro_fast = (on & 2) == 0; }
 // geometry: even nx (float2), tiles not mostly empty, 32-bit offsets; a z-slab needs 3 ghost planes per side (kernel B's halo)
 bool gsrb_pair_geom_ok(const GridX& g) {
-  return g_pair_on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.gnz >= 10 && (g.k1 - g.k0) >= 8 && (g.nz == g.gnz || g.k0 >= 3) && g.cs < (1L << 30);
+  return g_pair_on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.gnz >= 10 && (g.k1 - g.k0) >= 8 && (g.nz == g.gnz || g.k0 >= 2) && g.cs < (1L << 30);   // (z-slab: kernel A reads 2 planes below its first output plane, B 3 — wl_mg::pair_slab checks the level's ghost depth)
 }
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl) { return cl.on && gsrb_pair_geom_ok(g); }
 // 16-row tiles where the 32-row tiling cannot fill the chip for many rounds (WL_PAIR_ROWS=16|32 forces one: experiments)
@@ -59,8 +59,8 @@ static bool rows16(const GridX& g, int kernel = 0) {   // kernel: 1 = A, 2 = B (
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s) {
   return rows16(g, 1) ? pair16::gsrb_pair_A(emid, r, g, cl, s) : pair32::gsrb_pair_A(emid, r, g, cl, s);
 }
-int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s) {
-  return rows16(g, 1) ? pair16::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s) : pair32::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s);
+int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s, int xk0, int xk1) {
+  return rows16(g, 1) ? pair16::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1) : pair32::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1);
 }
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {

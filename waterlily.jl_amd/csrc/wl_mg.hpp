@@ -30,6 +30,7 @@ struct wl_mg {
   bool skip_fill = true;    // Vcycle!'s fill!(coarse.x,0) folded into the coarse level's Jacobi! (x = ω·ϵ instead of x += ω·ϵ)
   bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
   bool shift_pending = false;
+  bool deep_halo = true;     // z-slabs with >= 5 ghost planes: one r exchange (5 planes) per smooth! instead of r (2) + ϵ_mid (3) + r' (2)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
@@ -43,7 +44,7 @@ struct wl_mg {
   int build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels, wl_comm* c = nullptr);
   int halo(Level& v, float* a, int ncomp, hipStream_t s, int depth = 1) { return v.dist ? wl::halo(comm, a, v.x_, ncomp, depth, s) : 0; }
   // a distributed level whose smooth! runs as the blocked pair kernels (constant coefficients, 3 ghost planes)
-  bool pair_slab(const Level& v) const { return v.dist && use_fused && !perdir && wl::gsrb_pair_ok(v.x_, v.cl); }
+  bool pair_slab(const Level& v) const { return v.dist && v.g.k0 >= 3 && use_fused && !perdir && wl::gsrb_pair_ok(v.x_, v.cl); }
   ~wl_mg();
   int update(hipStream_t s);
   int smooth(int l, int it, float w, hipStream_t s, bool want_norms = false, bool* norms_done = nullptr);

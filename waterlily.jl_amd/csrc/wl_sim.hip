@@ -549,7 +549,8 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   int32_t ng[3] = {desc->dims[0] + 2, desc->dims[1] + 2, desc->D == 3 ? desc->dims[2] + 2 : 1};
   if (slab) {
     if (desc->u || desc->u0 || desc->f || desc->p || desc->sigma || desc->V || desc->mu0 || desc->mu1) { delete s; wl_set_error("slab simulations own their arrays"); return WL_EINVAL; }
-    const int rc = wl_grid_slab(&s->g, desc->D, ng, comm->rank, comm->size, 3);   // 3 ghost planes: QUICK needs 2, kernel B of the blocked smoother 3
+    static const int ghost = [] { const char* e = getenv("WL_SLAB_GHOST"); const int v = e ? atoi(e) : 5; return v >= 3 ? v : 5; }();
+    const int rc = wl_grid_slab(&s->g, desc->D, ng, comm->rank, comm->size, ghost);   // ghost planes: QUICK needs 2, kernel B of the blocked smoother 3, the one-exchange smooth! 5
     if (rc != 0) { delete s; return rc; }
   } else s->g = wl_grid_single(desc->D, ng);
   s->G = gx(s->g);
@@ -642,6 +643,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fuse_cfl") { s->use_fuse_cfl = value != 0; return 0; }
   if (n == "jacobi_march") { wl::jacobi_march_enable(value); return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
+  if (n == "deep_halo") { s->mg->deep_halo = value != 0; return 0; }
   if (n == "bcfold") { s->use_bcfold = value; return 0; }   // bit 0: projection tails, bit 1: tiled conv_diff!+BDIM!
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
