@@ -6,9 +6,13 @@ wall-bounded Taylor–Green vortex of SURVEY §8d (Float32, NoBody, remeasure=fa
 HBM when the timed region starts.  N=1 workload: 512³ (the size BASELINE.json's metric and the ≥60 %
 smoother target are quoted on); with --gpus N the same 512³ domain is cut into N z-slabs (strong scaling).
 
-Prints ONE JSON line (rank 0): metric/value + `roofline` (dominant kernel, HIP-event timed inside the timed
-region on the launch stream) + `cpu_baseline` (the oracle — a CPU restatement of the reference algorithm,
-kind "port" — timed on this box's host cores on a bounded 128³ sample of the same workload).
+`python bench.py --gpus N` needs no launcher: it starts its N ranks itself (torch.distributed.run children, one per GPU).
+
+Prints ONE JSON line (rank 0): metric/value + `roofline` (the finest-level smoother kernel pair, HIP-event timed inside the
+timed region on the launch stream; `frac` = the kernels' OWN algorithmic bytes ÷ time ÷ 8 TB/s, `traffic_frac` = PMC bytes,
+`op_equivalent` = the reference formulation's operation bytes ÷ the same time) + `cpu_baseline` (the oracle — a CPU restatement
+of the reference algorithm, kind "port" — timed on this box's host cores on bounded samples of the same workload: all cores at
+128³ and 256³, one thread at 128³).
 """
 import argparse
 import ctypes as C
