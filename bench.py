@@ -216,6 +216,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="HIP-event pairs around every phase of the step (phases_ms_per_step); the default run "
                     "only brackets the roofline kernels — each pair costs a few µs of stream time, ≈1 %% of a 512³ step with all of them on")
+    ap.add_argument("--no-phases", action="store_true", help="with WL_OPT_* switches set: keep the default (roofline kernels only) event pairs")
     ap.add_argument("--cpu-budget", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -268,7 +269,7 @@ def main():
         sim.mom_step_()
     sim.sync()
     n_warm = len(sim.pois_n)
-    all_phases = args.phases or any(k.startswith("WL_OPT_") for k in os.environ)
+    all_phases = args.phases or (any(k.startswith("WL_OPT_") for k in os.environ) and not args.no_phases)
     check(lib.wl_prof_enable(1 if all_phases else 2))
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -414,6 +414,45 @@ def test_pair_vcycle_with_fused_prolongation_is_bit_identical(w, oracle, N):
             assert np.array_equal(res["pair"][l][k], res["passes"][l][k]), ("pair vs passes", l, name)
 
 
+@pytest.mark.parametrize("N", [(66, 66, 66), (130, 66, 34), (34, 34, 34), (66, 18, 34), (258, 34, 18)])
+@pytest.mark.parametrize("const", [True, False])
+def test_lds_resident_coarse_tail_is_bit_identical(w, oracle, N, const):
+    """Vcycle! whose smallest levels run as ONE launch with r, x, ϵ held in LDS (k_vcycle_tail_lds; coefficients evaluated on
+    constant-coefficient hierarchies, loaded otherwise) vs the global-memory tail vs one launch per operation vs the oracle:
+    r, x and ϵ of every level bit for bit."""
+    import ctypes as C
+    rng = np.random.default_rng(71)
+    if const:
+        L = _const_L(N, (1, 1, 1))
+    else:
+        L = np.asfortranarray(rng.uniform(0.2, 1, size=N + (3,)).astype(np.float32))
+        L[5:9, 4:8, 3:7] = 0
+    oracle.BC(L, (0, 0, 0))
+    x0, z, r0 = F(N), F(N), F(N)
+    r0[1:-1, 1:-1, 1:-1] = rng.uniform(-1, 1, size=tuple(n - 2 for n in N)).astype(np.float32)
+    po = oracle.MultiLevelPoisson(x0.copy(order="F"), L.copy(order="F"), z.copy(order="F"))
+    po.field("r", 0)[...] = r0
+    po.Vcycle(0, 0.9); po.GaussSeidelRB(0, 4, 0.9)
+    lib = w.lib()
+    res = {}
+    for tag, tail, lds in (("lds", True, True), ("global", True, False), ("launches", False, True)):
+        xg, Lg, zg = w.to_device(x0), w.to_device(L), w.to_device(z)
+        pg = w.MultiLevelPoisson(xg, Lg, zg)
+        assert pg.level_is_const(0) == const
+        pg.set_fused(True, True, tail=tail, tail_lds=lds)
+        w._lib.check(lib.wl_h2d(lib.wl_mg_level_field(pg._h, 0, b"r"), r0.ctypes.data_as(C.c_void_p), r0.nbytes, w.core.stream()))
+        pg.Vcycle_(0, 0.9); pg.smooth_(0, 4, 0.9)
+        res[tag] = [(pg.levels[l].r, pg.levels[l].x, pg.levels[l].eps) for l in range(po.nlevels)]
+        pg.set_fused(True, True)
+    for l in range(po.nlevels):
+        for k, name in enumerate(("r", "x", "eps")):
+            assert np.array_equal(res["lds"][l][k], res["global"][l][k]), ("LDS tail vs global-memory tail", l, name)
+            if name != "eps" or l > 0:   # (level 0's ϵ is scratch the pair kernels may skip)
+                assert np.array_equal(res["lds"][l][k], res["launches"][l][k]), ("LDS tail vs launches", l, name)
+            if name != "eps":
+                assert np.array_equal(res["lds"][l][k], po.field(name, l)), ("LDS tail vs oracle", l, name)
+
+
 # ---------------------------------------------------------------- SURVEY row f4: single-level Poisson (pcg!, solver!)
 def poisson_setup_single_gpu(w, oracle, N):
     """Poisson_setup(Poisson,N)   test/test_poisson.jl:1-12 on the HIP path"""

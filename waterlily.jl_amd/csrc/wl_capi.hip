@@ -275,7 +275,7 @@ int wl_mg::tail(int first, float w, hipStream_t s) {
   const int n = (int)lv.size() - first;
   for (int q = 0; q < n; q++) {
     const Level& v = lv[(size_t)(first + q)];
-    h[q] = wl::TailLevelHost{v.x_, v.L, v.D, v.iD, v.x, v.eps, v.r, 0, 0, 0};
+    h[q] = wl::TailLevelHost{v.x_, v.L, v.D, v.iD, v.x, v.eps, v.r, 0, 0, 0, &v.cl};
     if (q + 1 < n) { const Level& c = lv[(size_t)(first + q + 1)]; h[q].cx = c.g.nx < v.g.nx; h[q].cy = c.g.ny < v.g.ny; h[q].cz = c.g.gnz < v.g.gnz; }
   }
   return wl::vcycle_tail(h, n, w, s);
@@ -586,7 +586,7 @@ int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 
   return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
 }
 int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
-int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; return 0; }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; wl::tail_lds_enable((on & 32) == 0); return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

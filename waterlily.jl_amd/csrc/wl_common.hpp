@@ -272,7 +272,8 @@ int shift_norms_dev(float* r, const GridX& g, const RedWs& ws, int slot_d, int s
 // coarse tail of the V-cycle in one launch (wl_poisson.hip)
 #define WL_TAIL_MAXLV 8
 #define WL_TAIL_CELLS 8192
-struct TailLevelHost { GridX g; const float* L; const float* D; const float* iD; float* x; float* eps; float* r; int cx, cy, cz; };
+struct TailLevelHost { GridX g; const float* L; const float* D; const float* iD; float* x; float* eps; float* r; int cx, cy, cz; const ConstL* cl = nullptr; };
+void tail_lds_enable(int on);   // 1 (default): the tail keeps r, x, ϵ of its levels in LDS; 0: the global-memory tail
 int vcycle_tail(const TailLevelHost* lv, int n, float w, hipStream_t s);
 int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* L, const float* Dg, const float* iD, const GridX& g, float a, int more, const RedWs& ws, hipStream_t s);
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);

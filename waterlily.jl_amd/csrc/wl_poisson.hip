@@ -705,6 +705,163 @@ __global__ void __launch_bounds__(1024) k_vcycle_tail(TailArgs a) {
     tail_smooth(v, a.w);
   }
 }
+// ---- the same tail with every level's r, x, ϵ resident in LDS (round 2) ---------------------------------------------------------
+// The tail above is pure latency: ≈36 phases, each a global load → compute → global store → barrier round trip through L2
+// (≈1.6 µs per phase, 57 µs per launch, twice per time step: 14 % of a 128³ step).  The arrays of all tail levels fit into one CU's LDS
+// (3 fields × ≤ 8192 cells × 4 B for the first level, ≈1/8 of that for each further one): they are loaded once, every phase runs
+// LDS → LDS, and r, x, ϵ of all levels are written back at the end (same final state of every array as the global-memory tail).
+// The statements per cell are those of the kernel above ⇒ bit-identical.  CL: every tail level has verified constant
+// coefficients (wl::ConstL) — L, D, iD are evaluated from the cell's indices instead of being loaded (identical bits, no global
+// access inside the phases at all); otherwise they are read from global memory (read-only: no store → load dependency).
+struct TailLds { int lo; float inx, iny; float c[3]; };          // LDS offset of the level's r (x and ϵ follow); 1/(nx-2), 1/(ny-2); ConstL::c
+struct TailArgsL { TailArgs a; TailLds q[WL_TAIL_MAXLV]; float tab[54 * WL_TAIL_MAXLV]; };   // tab: Dt[27], iDt[27] per level
+struct TailCoef { float lx, lxp, ly, lyp, lz, lzp, d, id; };
+template <bool CL>
+__device__ __forceinline__ TailCoef tail_coef(const TailLevel& v, const TailLds& q, const float* __restrict__ tb, int i, int j, int k, int o) {
+  TailCoef t;
+  if (CL) {
+    const GridX& g = v.g;
+    const int I0 = i + 1, I1 = j + 1, I2 = k + 1;
+    t.lx = wl::wl_cl_coef(I0, g.nx, q.c[0]); t.lxp = wl::wl_cl_coef(I0 + 1, g.nx, q.c[0]);
+    t.ly = wl::wl_cl_coef(I1, g.ny, q.c[1]); t.lyp = wl::wl_cl_coef(I1 + 1, g.ny, q.c[1]);
+    t.lz = wl::wl_cl_coef(I2, g.gnz, q.c[2]); t.lzp = wl::wl_cl_coef(I2 + 1, g.gnz, q.c[2]);
+    const int n = wl::wl_cl_cnt(I0, g.nx) + 3 * wl::wl_cl_cnt(I1, g.ny) + 9 * wl::wl_cl_cnt(I2, g.gnz);
+    t.d = tb[n]; t.id = tb[27 + n];
+  } else {
+    const GridX& g = v.g;
+    t.lx = v.L[o]; t.lxp = v.L[o + 1];
+    t.ly = v.L[g.cs + o]; t.lyp = v.L[g.cs + o + g.sy];
+    t.lz = v.L[2 * g.cs + o]; t.lzp = v.L[2 * g.cs + o + g.sz];
+    t.d = v.D[o]; t.id = v.iD[o];
+  }
+  return t;
+}
+template <class F>
+__device__ __forceinline__ void tail_inside_l(const GridX& g, const TailLds& q, F fn) {
+  const int nxi = g.nx - 2, nyi = g.ny - 2, nzi = g.nz - 2;
+  const int n = nxi * nyi * nzi, sy = (int)g.sy, sz = (int)g.sz;
+  for (int c = threadIdx.x; c < n; c += 1024) {
+    // c < 8192, extents < 8192: (c+½)·(1/n) lies ≥ 1/(2n) away from an integer, the Float32 error is ≤ 1e-3 ⇒ the truncation is exact
+    const int t = (int)(((float)c + 0.5f) * q.inx), i = 1 + c - t * nxi;
+    const int kk = (int)(((float)t + 0.5f) * q.iny), j = 1 + t - kk * nyi, k = 1 + kk;
+    fn(i, j, k, i + j * sy + k * sz);
+  }
+}
+template <bool CL>
+__device__ __forceinline__ void tail_smooth_l(const TailLevel& v, const TailLds& q, float* __restrict__ sm, const float* __restrict__ tb, float w) {
+  const GridX& g = v.g;
+  const int cs = (int)g.cs, sy = (int)g.sy, sz = (int)g.sz;
+  float* R = sm + q.lo; float* X = R + cs; float* E = X + cs;
+  tail_inside_l(g, q, [&](int i, int j, int k, int o) { E[o] = R[o] * tail_coef<CL>(v, q, tb, i, j, k, o).id; });
+  __syncthreads();
+  for (int kk0 = 1; kk0 <= 4; kk0++) {
+    tail_inside_l(g, q, [&](int i, int j, int k, int o) {
+      if (((i + j + k + 3 + kk0) & 1) == 0) return;
+      if (k + 1 > 2 * (g.gnz / 2) - 1) return;                                  // quirk Q4
+      const TailCoef t = tail_coef<CL>(v, q, tb, i, j, k, o);
+      float s = R[o];
+      s -= (E[o - 1] * t.lx + E[o + 1] * t.lxp);
+      s -= (E[o - sy] * t.ly + E[o + sy] * t.lyp);
+      s -= (E[o - sz] * t.lz + E[o + sz] * t.lzp);
+      E[o] = s * t.id;
+    });
+    __syncthreads();
+  }
+  tail_inside_l(g, q, [&](int i, int j, int k, int o) {
+    const TailCoef t = tail_coef<CL>(v, q, tb, i, j, k, o);
+    float s = E[o] * t.d;
+    s += (E[o - 1] * t.lx + E[o + 1] * t.lxp);
+    s += (E[o - sy] * t.ly + E[o + sy] * t.lyp);
+    s += (E[o - sz] * t.lz + E[o + sz] * t.lzp);
+    R[o] = R[o] - w * s;
+    X[o] = X[o] + w * E[o];
+  });
+  __syncthreads();
+}
+template <bool CL>
+__global__ void __launch_bounds__(1024) k_vcycle_tail_lds(TailArgsL b) {
+  extern __shared__ float sm[];
+  const TailArgs& a = b.a;
+  float* tb = sm;                                                               // [level][54]: Dt, iDt
+  if (CL) {   // the tables are indexed per lane: read them through the kernel-argument segment's address rather than as scalars
+    const float* kt = (const float*)((const char*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(TailArgsL, tab));
+    for (int q = threadIdx.x; q < 54 * a.n; q += 1024) tb[q] = kt[q];
+  }
+  // ---- load r, x, ϵ of every level (ghost cells included: the stencils read ϵ and x_c there)
+  for (int l = 0; l < a.n; l++) {
+    const TailLevel& v = a.lv[l];
+    const int cs = (int)v.g.cs;
+    float* R = sm + b.q[l].lo;
+    for (int o = threadIdx.x; o < cs; o += 1024) { R[o] = v.r[o]; R[cs + o] = v.x[o]; R[2 * cs + o] = v.eps[o]; }
+  }
+  __syncthreads();
+  // ---- down: Jacobi!(fine); restrict!(coarse.r, fine.r); coarse.x = 0            src/MultiLevelPoisson.jl:92-95
+  for (int l = 0; l + 1 < a.n; l++) {
+    const TailLevel& f = a.lv[l]; const TailLevel& c = a.lv[l + 1];
+    const int fcs = (int)f.g.cs, fsy = (int)f.g.sy, fsz = (int)f.g.sz, ccs = (int)c.g.cs;
+    float* R = sm + b.q[l].lo; float* X = R + fcs; float* E = X + fcs;
+    float* Rc = sm + b.q[l + 1].lo; float* Xc = Rc + ccs;
+    const float* tl = tb + 54 * l;
+    tail_inside_l(f.g, b.q[l], [&](int i, int j, int k, int o) { E[o] = R[o] * tail_coef<CL>(f, b.q[l], tl, i, j, k, o).id; });
+    __syncthreads();
+    tail_inside_l(f.g, b.q[l], [&](int i, int j, int k, int o) {
+      const TailCoef t = tail_coef<CL>(f, b.q[l], tl, i, j, k, o);
+      float s = E[o] * t.d;
+      s += (E[o - 1] * t.lx + E[o + 1] * t.lxp);
+      s += (E[o - fsy] * t.ly + E[o + fsy] * t.lyp);
+      s += (E[o - fsz] * t.lz + E[o + fsz] * t.lzp);
+      R[o] = R[o] - 1.f * s;
+      X[o] = X[o] + 1.f * E[o];
+    });
+    __syncthreads();
+    for (int o = threadIdx.x; o < ccs; o += 1024) Xc[o] = 0.f;
+    tail_inside_l(c.g, b.q[l + 1], [&](int i, int j, int k, int o) {
+      const int fi = f.cx ? 2 * i - 1 : i, fj = f.cy ? 2 * j - 1 : j, fk = f.cz ? 2 * k - 1 : k;
+      float s = 0.f;
+      for (int cc = 0; cc <= f.cz; cc++)
+        for (int bb = 0; bb <= f.cy; bb++)
+          for (int aa = 0; aa <= f.cx; aa++) s += R[(fi + aa) + (fj + bb) * fsy + (fk + cc) * fsz];
+      Rc[o] = s;
+    });
+    __syncthreads();
+  }
+  // ---- bottom and up: smooth!(coarse) ; prolongate!+increment!(fine;ω) ; ... ; smooth!(first level)            :96-100
+  for (int l = a.n - 1; l >= 0; l--) {
+    const TailLevel& v = a.lv[l];
+    const float* tl = tb + 54 * l;
+    if (l + 1 < a.n) {
+      const TailLevel& c = a.lv[l + 1];
+      const GridX& gf = v.g;
+      const int cs = (int)gf.cs, csy = (int)c.g.sy, csz = (int)c.g.sz;
+      float* R = sm + b.q[l].lo; float* X = R + cs;
+      const float* Xc = sm + b.q[l + 1].lo + (int)c.g.cs;
+      tail_inside_l(gf, b.q[l], [&](int i, int j, int k, int o) {
+        const TailCoef t = tail_coef<CL>(v, b.q[l], tl, i, j, k, o);
+        // down(I) of wl down_off (0-based (i+1)/2 in a coarsened direction); gk = 0 on tail levels
+        auto E = [&](int ii, int jj, int kk) -> float {
+          const int ci = v.cx ? (ii + 1) / 2 : ii, cj = v.cy ? (jj + 1) / 2 : jj, ck = v.cz ? (kk + 1) / 2 : kk;
+          return Xc[ci + cj * csy + ck * csz];
+        };
+        const float e0 = E(i, j, k);
+        float s = e0 * t.d;
+        s += (E(i - 1, j, k) * t.lx + E(i + 1, j, k) * t.lxp);
+        s += (E(i, j - 1, k) * t.ly + E(i, j + 1, k) * t.lyp);
+        s += (E(i, j, k - 1) * t.lz + E(i, j, k + 1) * t.lzp);
+        R[o] = R[o] - a.w * s;
+        X[o] = X[o] + a.w * e0;
+      });
+      __syncthreads();
+    }
+    tail_smooth_l<CL>(v, b.q[l], sm, tl, a.w);
+  }
+  // ---- write r, x, ϵ of every level back
+  for (int l = 0; l < a.n; l++) {
+    const TailLevel& v = a.lv[l];
+    const int cs = (int)v.g.cs;
+    const float* R = sm + b.q[l].lo;
+    for (int o = threadIdx.x; o < cs; o += 1024) { v.r[o] = R[o]; v.x[o] = R[cs + o]; v.eps[o] = R[2 * cs + o]; }
+  }
+}
 // restrictL!  a[I,i] = restrictL(I,i,b,c)   src/MultiLevelPoisson.jl:9-11,20-26,45  (BC!(a,0) applied afterwards by bc_vec)
 template <int D>
 __global__ void k_restrictL(GridX gc, GridX gf, float* __restrict__ a, const float* __restrict__ b, int cx, int cy, int cz) {
@@ -938,11 +1095,37 @@ int jacobi_pp(float* rout, const float* r, float* x, const float* L, const float
   WL_LAUNCH_CHECK(); return 0;
 }
 // if (levels below `first` exist) Vcycle!(first); smooth!(first)  — for the levels handed over in `lv` (coarsening flags in lv[l].c*)
+int g_tail_lds = 1;
+void tail_lds_enable(int on) { g_tail_lds = on; }
 int vcycle_tail(const TailLevelHost* lv, int n, float w, hipStream_t s) {
   if (n < 1 || n > WL_TAIL_MAXLV) { wl_set_error("vcycle_tail: bad level count"); return WL_EINVAL; }
-  TailArgs a; a.n = n; a.w = w;
+  TailArgsL b; TailArgs& a = b.a; a.n = n; a.w = w;
   for (int l = 0; l < n; l++) a.lv[l] = TailLevel{lv[l].g, lv[l].L, lv[l].D, lv[l].iD, lv[l].x, lv[l].eps, lv[l].r, lv[l].cx, lv[l].cy, lv[l].cz};
-  hipLaunchKernelGGL(k_vcycle_tail, dim3(1), dim3(1024), 0, s, a);
+  // LDS-resident variant: r, x, ϵ of all levels (+ the coefficient tables) must fit into one CU's LDS
+  bool cl = true, fits = g_tail_lds != 0;
+  long lo = 54 * WL_TAIL_MAXLV;
+  for (int l = 0; l < n; l++) {
+    const GridX& g = lv[l].g;
+    if (g.D != 3 || g.gk != 0 || g.nz != g.gnz || g.nx < 3 || g.ny < 3 || g.nz < 3 || g.cs > WL_TAIL_CELLS) fits = false;
+    cl = cl && lv[l].cl && lv[l].cl->on;
+    b.q[l].lo = (int)lo; b.q[l].inx = 1.f / (float)(g.nx - 2); b.q[l].iny = 1.f / (float)(g.ny - 2);
+    for (int c = 0; c < 3; c++) b.q[l].c[c] = (lv[l].cl && lv[l].cl->on) ? lv[l].cl->c[c] : 0.f;
+    for (int t = 0; t < 27; t++) { b.tab[54 * l + t] = (lv[l].cl && lv[l].cl->on) ? lv[l].cl->Dt[t] : 0.f; b.tab[54 * l + 27 + t] = (lv[l].cl && lv[l].cl->on) ? lv[l].cl->iDt[t] : 0.f; }
+    lo += 3 * g.cs;
+  }
+  const size_t bytes = (size_t)lo * sizeof(float);
+  if (fits && bytes <= 156 * 1024) {
+    static bool attr[2] = {false, false};
+    if (!attr[cl ? 1 : 0]) {   // dynamic LDS beyond 64 KiB has to be requested once per kernel
+      WL_HIP(cl ? hipFuncSetAttribute((const void*)k_vcycle_tail_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024)
+                : hipFuncSetAttribute((const void*)k_vcycle_tail_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+      attr[cl ? 1 : 0] = true;
+    }
+    if (cl) hipLaunchKernelGGL(k_vcycle_tail_lds<true>, dim3(1), dim3(1024), bytes, s, b);
+    else hipLaunchKernelGGL(k_vcycle_tail_lds<false>, dim3(1), dim3(1024), bytes, s, b);
+  } else {
+    hipLaunchKernelGGL(k_vcycle_tail, dim3(1), dim3(1024), 0, s, a);
+  }
   WL_LAUNCH_CHECK(); return 0;
 }
 // one stage of pcg! ; stages 0-2 leave their dot product in ws.res_d[0]

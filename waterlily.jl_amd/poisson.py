@@ -185,11 +185,11 @@ class MultiLevelPoisson:
         """smooth!(levels[l];ω) = GaussSeidelRB!   src/MultiLevelPoisson.jl:106"""
         check(lib().wl_mg_smooth(self._h, int(l), int(it), float(w), stream()))
 
-    def set_fused(self, on, pair=True, tail=None):
+    def set_fused(self, on, pair=True, tail=None, tail_lds=True):
         """on: temporally blocked smoother; pair: its two-cells-per-thread variant on constant-coefficient levels;
-        tail: the smallest levels of the V-cycle in one launch (default: same as `on`)"""
+        tail: the smallest levels of the V-cycle in one launch (default: same as `on`); tail_lds: that launch keeps its levels in LDS"""
         tail = bool(on) if tail is None else bool(tail)
-        check(lib().wl_mg_set_fused(self._h, int(bool(on)) | (0 if pair else 4) | (0 if tail else 8)))
+        check(lib().wl_mg_set_fused(self._h, int(bool(on)) | (0 if pair else 4) | (0 if tail else 8) | (0 if tail_lds else 32)))
 
     def level_is_const(self, l):
         return bool(lib().wl_mg_level_is_const(self._h, l))
