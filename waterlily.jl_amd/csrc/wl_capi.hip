@@ -182,12 +182,16 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     const bool pro = p.pend;
     Level& coarse = lv[(size_t)(pro ? l + 1 : l)];
     p.pend = false;
+    bool xdef[3] = {false, false, false};                    // per range: `x += ω·x_c↓` handed from kernel A to kernel B (wl::XDefer)
+    const wl::XDefer xd{coarse.x, coarse.x_, w};
     {
       ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s);
       for (int i = 0; i < 3; i++) if (parts[i].b > parts[i].a) {
         const GridX g = sub(parts[i].a, parts[i].b);
-        if (pro) WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, g, coarse.x_, w, *parts[i].cl, s));
-        else WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, g, *parts[i].cl, s));
+        if (pro) {
+          xdef[i] = use_xdefer && wl::gsrb_pair_B_ok(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, g, *parts[i].cl);
+          WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, g, coarse.x_, w, *parts[i].cl, s, -(1 << 30), 1 << 30, &xdef[i]));
+        } else WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, g, *parts[i].cl, s));
       }
     }
     {
@@ -199,7 +203,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
         const GridX g = sub(parts[i].a, parts[i].b);
         const RedWs* nws = want_norms ? &ws : nullptr;
         if (want_norms) norm_slots |= 1 << i;
-        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s));
+        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s, xdef[i] ? &xd : nullptr));
         else WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s));
       }
     }
@@ -212,6 +216,8 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     if (p.pend) {
       Level& coarse = lv[(size_t)l + 1];
       p.pend = false;
+      bool xdef = use_xdefer && wl::gsrb_pair_B_ok(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.x_, p.cl);   // `x += ω·x_c↓` handed from kernel A to kernel B
+      const wl::XDefer xd{coarse.x, coarse.x_, w};
       // z-slab: the tile pipeline recomputes the neighbour's planes it needs, so the exchanges are r (2 planes) before A and
       // ϵ_mid (3 planes) + r' (2 planes) before B — instead of one exchange per colour sweep
       if (p.dist && deep_halo && p.g.k0 >= 5 && p.g.k1 - p.g.k0 >= 5) {
@@ -220,14 +226,14 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
         // instead of two, ≈6 redundant planes of kernel A per rank.
         WL_TRY(halo(p, p.r, 1, s, 5));
         GridX ge = p.x_; ge.k0 = p.x_.k0 - 3; ge.k1 = p.x_.k1 + 3;
-        { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, ge, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1)); }
-        { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
+        { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, ge, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1, &xdef)); }
+        { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s, xdef ? &xd : nullptr)); }
         norm_slots = 0;
         if (norms_done) *norms_done = want_norms;
         return 0;
       }
       WL_TRY(halo(p, p.r, 1, s, 2));
-      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s)); }
+      { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, p.x_, coarse.x_, w, p.cl, s, -(1 << 30), 1 << 30, &xdef)); }
       {   // one RCCL group for both arrays: one exchange latency instead of two
         const bool grp = comm && comm->size > 1 && p.dist;
         if (grp) { WL_TRY(comm->group_begin()); comm->n_halo++; }   // one network round for both arrays
@@ -236,7 +242,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
         if (grp) { const int rc2 = comm->group_end(); if (rc == 0) rc = rc2; }
         WL_TRY(rc);
       }
-      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s)); }
+      { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s, xdef ? &xd : nullptr)); }
     } else {
       WL_TRY(halo(p, p.r, 1, s, 2));
       { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, p.x_, p.cl, s)); }
@@ -586,7 +592,7 @@ int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 
   return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
 }
 int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
-int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; wl::tail_lds_enable((on & 32) == 0); return 0; }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; wl::tail_lds_enable((on & 32) == 0); mg->use_xdefer = (on & 64) == 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

@@ -279,9 +279,13 @@ int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* 
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s);
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
-                     int xk0 = -(1 << 30), int xk1 = 1 << 30);
+                     int xk0 = -(1 << 30), int xk1 = 1 << 30, bool* defer_x = nullptr);   // defer_x (in/out): leave `x += ω·x_c↓` to kernel B (cleared if this path cannot)
+// The V-cycle's `x += ω·x_c↓` handed from kernel A to kernel B of the same smooth! (pair kernels only): A leaves x alone, B applies both
+// increments of x in order — x is read and written once per smooth! instead of twice.
+struct XDefer { const float* xc; GridX gc; float w; };
+bool gsrb_pair_B_ok(const float* eps, const float* rout, const float* x, const float* emid, const float* r, const GridX& g, const ConstL& cl);
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
-                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
+                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s, const XDefer* xd = nullptr);   // xd: only when gsrb_pair_B_ok
 int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStream_t s);
 // pair variant of the blocked smoother for constant-coefficient levels (wl_fused2.hip); chosen inside gsrb_fused_* when eligible
 void gsrb_pair_enable(int on);
@@ -291,7 +295,7 @@ int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, h
 int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
                     int xk0 = -(1 << 30), int xk1 = 1 << 30);   // [xk0,xk1): planes on which x is updated (default: every output plane)
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
-                const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s);
+                const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s, const XDefer* xd = nullptr);
 int restrict_(float* a, const GridX& gc, const float* b, const GridX& gf, hipStream_t s);
 int prolongate(float* a, const GridX& gf, const float* b, const GridX& gc, hipStream_t s);
 int prolong_increment(float* r, float* x, float* eps, const float* xc, const float* L, const float* D, const GridX& gf, const GridX& gc, float w, bool write_eps, hipStream_t s);

@@ -326,8 +326,12 @@ int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, co
 }
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
-                     int xk0, int xk1) {
-  if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1);
+                     int xk0, int xk1, bool* defer_x) {
+  if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) {
+    if (defer_x && *defer_x) { xk0 = 0; xk1 = 0; }    // x is left to kernel B (wl::XDefer)
+    return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1);
+  }
+  if (defer_x) *defer_x = false;
   if (g.nz != g.gnz) { wl_set_error("blocked smoother on a z-slab level needs the pair kernels"); return WL_EINVAL; }
   const int zc = zchunk_for(g, 2);
   const int nt = ztile_count(g.nx, g.ny, 2), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;
@@ -338,9 +342,13 @@ int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const f
   WL_LAUNCH_CHECK(); return 0;
 }
 // ws != NULL: also leaves L₁/L∞ of the new residual in ws->res_d[slot_d] / ws->res_f[slot_f] (device); eps == NULL: final ϵ not stored
+bool gsrb_pair_B_ok(const float* eps, const float* rout, const float* x, const float* emid, const float* r, const GridX& g, const ConstL& cl) {
+  return gsrb_pair_ok(g, cl) && al8(eps, rout, x, emid, r);
+}
 int gsrb_fused_B(float* eps, float* rout, float* x, const float* emid, const float* r, const float* L, const GridX& g, float w,
-                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {
-  if (gsrb_pair_ok(g, cl) && al8(eps, rout, x, emid, r)) return gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s);
+                 const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s, const XDefer* xd) {
+  if (gsrb_pair_B_ok(eps, rout, x, emid, r, g, cl)) return gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s, xd);
+  if (xd) { wl_set_error("gsrb_fused_B: a deferred x increment needs the pair kernel"); return WL_EINVAL; }
   if (g.nz != g.gnz) { wl_set_error("blocked smoother on a z-slab level needs the pair kernels"); return WL_EINVAL; }
   const int zc = zchunk_for(g, 3);
   const int nt = ztile_count(g.nx, g.ny, 3), per = (nt + 7) >> 3, nch = (g.k1 - g.k0 + zc - 1) / zc;

@@ -63,7 +63,8 @@ int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const fl
   return rows16(g, 1) ? pair16::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1) : pair32::gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1);
 }
 int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const float* r, const GridX& g, float w,
-                const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s) {
-  return rows16(g, 2) ? pair16::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s) : pair32::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s);
+                const RedWs* ws, int slot_d, int slot_f, const ConstL& cl, hipStream_t s, const XDefer* xd) {
+  if (xd && xd->gc.cs >= (1L << 30)) { wl_set_error("gsrb_pair_B: coarse level too large for 32-bit offsets"); return WL_EINVAL; }
+  return rows16(g, 2) ? pair16::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s, xd) : pair32::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s, xd);
 }
 }  // namespace wl

@@ -33,6 +33,7 @@ struct wl_mg {
   bool deep_halo = true;     // z-slabs with >= 5 ghost planes: one r exchange (5 planes) per smooth! instead of r (2) + ϵ_mid (3) + r' (2)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
+  bool use_xdefer = true;   // pair smoother: the V-cycle's `x += ω·x_c↓` is applied by kernel B together with its own increment (wl::XDefer)
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
   bool tail_ok(int first) const;
   int tail(int first, float w, hipStream_t s);

@@ -632,6 +632,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "constl") { s->mg->use_constl = value != 0; return s->mg->update(0); }
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
   if (n == "tail_lds") { wl::tail_lds_enable(value); return 0; }
+  if (n == "xdefer") { s->mg->use_xdefer = value != 0; return 0; }
   if (n == "skip_fill") { s->mg->skip_fill = value != 0; return 0; }
   if (n == "defer_shift") { s->mg->defer_shift = value != 0; return 0; }
   if (n == "zsplit") {   // 0 off, 1 default size gate, 2 levels of any size, v >= 4: levels of at least v·2^20 cells (takes effect at the next update!)
