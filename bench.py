@@ -38,6 +38,9 @@ BYTES_KERNEL = {
     ("A_pro", True): 20.5,    # R r,x,x_c/8  W r',x,ϵ_mid
     ("B", False): 32.0,   # R ϵ_mid,r,L₁₋₃,x  W r',x
     ("B", True): 20.0,    # R ϵ_mid,r,x  W r',x
+    # pair kernels with the V-cycle's `x += ω·x_c↓` handed from A to B (wl::XDefer, the default): x makes one round trip per smooth!
+    ("A_pro_xd", True): 12.5,   # R r,x_c/8  W r',ϵ_mid
+    ("B_xd", True): 20.5,       # R ϵ_mid,r,x,x_c/8  W r',x
 }
 
 
@@ -151,8 +154,9 @@ def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
     pro_fused = prof["prolong_increment"]["launches"] == 0       # the V-cycle's prolongate!+increment! is folded into kernel A
     pair_ms = ka_ms + kb_ms
     bytes_op = BYTES_OP_GSRB + (BYTES_OP_PROLONG_INC if pro_fused else 0.0)
-    bytes_a = BYTES_KERNEL[("A_pro" if pro_fused else "A", const0)]
-    bytes_b = BYTES_KERNEL[("B", const0)]
+    x_deferred = bool(pro_fused and const0 and kind0 == 2 and os.environ.get("WL_OPT_xdefer", "1") != "0")
+    bytes_a = BYTES_KERNEL[(("A_pro_xd" if x_deferred else "A_pro") if pro_fused else "A", const0)]
+    bytes_b = BYTES_KERNEL[("B_xd" if x_deferred else "B", const0)]
     gbs = lambda by, ms: by * ncell / (ms * 1e-3) / 1e9
     traffic, tsrc, tper = None, None, {}
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
@@ -175,7 +179,7 @@ def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
         "bytes_per_cell": own, "bytes_definition": "the kernels' own algorithmic bytes per interior cell and launch pair (distinct elements each launch must read + write; "
                           "L, D, iD are evaluated from the cell position on constant-coefficient levels) — see kernels.*",
         "avg_launch_ms": pair_ms, "launches": prof["gsrb_B"]["launches"],
-        "constant_coefficient_kernels": const0,
+        "constant_coefficient_kernels": const0, "x_increment_deferred_to_B": x_deferred,
         "op_equivalent": {"bytes_per_cell": bytes_op, "achieved": gbs(bytes_op, pair_ms), "frac": gbs(bytes_op, pair_ms) / HBM_PEAK_GBS,
                           "what": "reference-defined operation bytes (SURVEY §8d: GaussSeidelRB! 40" + (" + prolongate!/increment! 36.5" if pro_fused else "")
                                   + " B/cell) ÷ the same time — the rate the reference's formulation would need for this work; NOT bytes moved"},
@@ -282,6 +286,18 @@ def main():
     ncell = float(N) ** 3
     pn = sim.pois_n[n_warm:]
     roof = build_roofline(prof, ncell, bool(sim.const_levels()[0]), sim.smoother_kinds()[0], N, use_traffic=True)
+    # the practical ceiling of kernel B's read/write mix on THIS device (a trivial kernel with the same streams and access shape), measured
+    # after the timed region; memory of the simulation is still allocated, so the probe box is at most 512³ (2 GiB)
+    try:
+        import ctypes as C
+        pg = C.c_double()
+        check(lib.wl_probe_mix(min(512, max(64, (N // 64) * 64)), 5, C.byref(pg), None))
+        roof["probe"] = {"what": "wl_probe_mix: 3 fields read + 2 written (20 B/cell) in kernel B's access shape (64x32-cell tiles, z-march), no arithmetic — "
+                                 "the practical ceiling of this mix on this device; `peak` stays the 8 TB/s specification",
+                         "achieved": pg.value, "unit": "GB/s", "frac_of_peak": pg.value / HBM_PEAK_GBS,
+                         "smoother_traffic_vs_probe": (roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / pg.value) if roof.get("traffic") else None}
+    except Exception as e:      # the probe is context for the reader, not part of the measurement
+        roof["probe"] = {"error": str(e)}
     out = {
         "metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": ncell * args.steps / el, "unit": "cells*steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,

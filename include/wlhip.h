@@ -283,6 +283,10 @@ int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm);
  *        9 / 10 fine-level kernels A / B of the temporally blocked smoother (wl_fused.hip)                        */
 enum { WL_PROF_GS_SWEEP = 0, WL_PROF_SMOOTH = 1, WL_PROF_JACOBI = 2, WL_PROF_CONVDIFF = 3, WL_PROF_RESIDUAL = 4,
        WL_PROF_BDIM = 5, WL_PROF_PROLONG = 6, WL_PROF_COARSE = 7, WL_PROF_STEP = 8, WL_PROF_GS_A = 9, WL_PROF_GS_B = 10, WL_PROF_NSLOTS = 11 };
+/* Bandwidth probe for the roofline report (wl_probe.hip): smoother kernel B's memory mix (3 fields read, 2 written, 20 B/cell) in its
+ * access shape (64×32-cell tiles, z-march) with trivial arithmetic on an n³ box (n a multiple of 64; allocates and frees 16·n³ bytes).
+ * *gbs = 20·n³ B ÷ average launch time over `reps` launches: the practical ceiling of that mix on this device. */
+int wl_probe_mix(int n, int reps, double* gbs, void* stream);
 int wl_prof_enable(int on);                                     /* 0 off, 1 all slots, 2 only slots 9 and 10 (each event pair costs a few µs of
                                                                     stream time); also resets all slots */
 int wl_prof_read(int slot, int* host_count, double* host_total_ms);   /* synchronises the device */
