@@ -129,7 +129,9 @@ int wl_mg::update(hipStream_t s) {                                              
   // constant-coefficient detection (exact, on device): only the levels that run the specialised kernels are checked
   for (size_t l = 0; l < lv.size(); l++) {
     lv[l].cl.on = 0; lv[l].part = false;
-    if (use_constl && !perdir && (l == 0 || wl::gsrb_fused_ok(lv[l].x_, perdir, lv[l].dist) || (lv[l].dist && wl::gsrb_pair_geom_ok(lv[l].x_)))) {
+    // (the levels of the single-launch tail too, when the finest level passed: the LDS-resident tail then evaluates L, D, iD instead of loading them)
+    const bool tail_level = l > 0 && use_tail && lv[0].cl.on && lv[l].g.D == 3 && !lv[l].dist && lv[l].x_.cs <= WL_TAIL_CELLS;
+    if (use_constl && !perdir && (l == 0 || tail_level || wl::gsrb_fused_ok(lv[l].x_, perdir, lv[l].dist) || (lv[l].dist && wl::gsrb_pair_geom_ok(lv[l].x_)))) {
       WL_TRY(wl::check_const_L(lv[l].L, lv[l].x_, &lv[l].cl, (int*)(ws.res_f + 7), s));
       if (lv[l].dist && comm && comm->size > 1) {   // every rank must take the same path (the slab kernels differ in their halo exchanges)
         const float bad = lv[l].cl.on ? 0.f : 1.f; float any = 1.f;

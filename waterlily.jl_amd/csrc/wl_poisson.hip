@@ -994,7 +994,7 @@ int project_cfl_split(float* uout, const float* uin, const float* L, const float
 // host-synchronising (update! time only): reads one interior face value per component, then verifies the whole array on device
 int check_const_L(const float* L, const GridX& g, ConstL* out, int* dev_flag, hipStream_t s) {
   out->on = 0; out->c[0] = out->c[1] = out->c[2] = 0.f;
-  if (g.nx < 5 || g.ny < 5 || (g.D == 3 && (g.k1 - g.k0) < 1)) return 0;
+  if (g.nx < 4 || g.ny < 4 || (g.D == 3 && (g.k1 - g.k0) < 1)) return 0;   // (4: one face per direction is not a wall face)
   // a cell whose lower faces are not wall faces in any direction: Julia index 3 in x,y and (globally) >= 3 in z
   int kk = (g.D == 3) ? g.k0 + ((g.gk + g.k0 + 1 >= 3) ? 0 : 1) : 0;
   if (g.D == 3 && (kk >= g.k1 || g.gk + kk + 1 >= g.gnz)) return 0;
