@@ -706,6 +706,33 @@ def test_zsplit_smoother_on_body_levels_is_bit_identical(w, exitBC):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_tiled_conv_diff_on_the_body_free_planes_is_bit_identical(w, scheme):
+    """conv_diff!+BDIM! with a body: the planes on which no workgroup is near the body, keeps f or loads μ₀ are NoBody planes bit for bit and
+    run the LDS-tiled kernel (two plane ranges, below and above the body), the planes in between the gather kernel with the body masks.
+    Same u, p and pois.n as the gather kernel over the whole domain; the split follows the body when it moves along z."""
+    n = (96, 48, 112)
+    R = 6.0
+    res = {}
+    for bt in (1, 0):
+        sim = w.FusedSimulation(n, (1, 0, 0), 2 * R, U=1, nu=2 * R / 250, has_body=True, lam=scheme)
+        sim.set_option("body_tile", bt)
+        sim.set_option("convt_min", 0)          # no size gate: the tiled kernel on this small box, several z-chunks per range
+        sim.measure_sphere_((n[0] / 4, n[1] / 2 - 1, 40.0), R, 1.0)
+        for _ in range(2):
+            sim.mom_step_()
+        sim.measure_sphere_((n[0] / 4 + 1.5, n[1] / 2, 70.5), R, 1.0)
+        for _ in range(2):
+            sim.mom_step_()
+        sim.measure_sphere_((n[0] / 4 + 1.5, n[1] / 2, 10.5), R, 1.0)     # close to the lower wall: only the upper range is long enough
+        sim.mom_step_()
+        res[bt] = (sim.field("u"), sim.field("p"), sim.pois_n)
+        sim.set_option("body_tile", 1)
+    assert res[0][2] == res[1][2]
+    assert np.isfinite(res[1][0]).all()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 BODIES_3D = [
     ("cylinder", (11.0, 13.5, 0.0), 4.0, 2),                                   # along z: the circle of the reference's 2-D cases, extruded
     ("cylinder", (0.0, 14.0, 12.5), 3.5, 0),                                   # along x

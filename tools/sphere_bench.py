@@ -15,6 +15,9 @@ lib = w.lib()
 check(lib.wl_init(0))
 R, c = N / 8, (N / 2 - 1,) * 3
 sim = w.FusedSimulation((N, N, N), (1, 0, 0), 2 * R, U=1, nu=2 * R / 3700, has_body=True)
+for key, val in os.environ.items():      # A/B switches: WL_OPT_<option of wl_sim_set_option>=value (before measure!: some act at update! time)
+    if key.startswith("WL_OPT_"):
+        sim.set_option(key[7:], int(val))
 sim.measure_sphere_(c, R, 1.0)
 for _ in range(5):
     sim.mom_step_()

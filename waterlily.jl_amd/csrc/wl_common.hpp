@@ -228,7 +228,10 @@ int bdim_f(float* f, const float* u0, const float* V, const GridX& g, float dt, 
 int bdim_u(float* u, const float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float pre, float post, hipStream_t s, const unsigned char* far = nullptr);
 size_t body_mask_bytes(const GridX& g);
 int conv_diff_bdim_body(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                        float dt, float pre, float post, const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, int nbm, int store_all, hipStream_t s);
+                        float dt, float pre, float post, const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, int nbm, int store_all, hipStream_t s,
+                        int dz0 = 0, int dz1 = -1);   // dz0..dz1: body_masks_planes (planes outside run the tiled NoBody kernel)
+int body_masks_planes(const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, const GridX& g, int* dz, hipStream_t s);
+void conv_body_tile_enable(int on);
 int body_masks_nbm(const GridX& g);
 int body_masks(unsigned char* near, unsigned char* needf, unsigned char* m0var, const float* V, const float* mu1, const float* mu0, const GridX& g, hipStream_t s);
 int bdim_near(float* uout, const float* uin, const float* u0, float* f, const float* V, const float* mu0, const float* mu1, const GridX& g, float dt, float pre, float post,

@@ -733,11 +733,46 @@ int conv_diff_bdim(float* f, const float* u_adv, float* Phi, const float* u0, co
   return conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd, ka, kb, q1, fold);
 }
 // conv_diff!+BDIM! for a flow with a body (see k_conv_diff<…,FUSE=2>): u_out ≠ u_adv; f is an output array (raw r near the body)
+// dz0..dz1 (inclusive; dz1 < dz0: unknown): the planes on which any workgroup is near the body, keeps f or has a μ₀ off the NoBody pattern
+// (body_masks_planes).  Every other plane is a NoBody plane bit for bit (μ₁ ≡ 0, V ≡ 0, μ₀ = the wall pattern, f not read by anyone):
+// those planes run the LDS-tiled kernel (wl_convt.hip) in its NoBody form, the planes dz0..dz1 this file's gather kernel (FUSE=2).
+int g_body_tile = 1;
+void conv_body_tile_enable(int on) { g_body_tile = on; }
 int conv_diff_bdim_body(float* f, const float* u_adv, float* Phi, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, unsigned per, int scheme,
-                        float dt, float pre, float post, const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, int nbm, int store_all, hipStream_t s) {
+                        float dt, float pre, float post, const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, int nbm, int store_all, hipStream_t s,
+                        int dz0, int dz1) {
   if (u_out == u_adv || !near || !needf || !m0var || !f) { wl_set_error("conv_diff_bdim_body: bad arguments"); return WL_EINVAL; }
   BdimArgs bd{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, 0, {0.f, 0.f, 0.f}, near, needf, nbm, store_all, m0var};
+  if (g.D == 3 && g_body_tile && !store_all && per == 0 && dz1 >= dz0 && g.nz == g.gnz) {
+    int na = dz0 > g.k0 ? dz0 : g.k0, nb = dz1 + 1 < g.k1 ? dz1 + 1 : g.k1;        // gather range [na,nb)
+    if (na - g.k0 < 8) na = g.k0;                                                     // far ranges too short for a march join the gather range
+    if (g.k1 - nb < 8) nb = g.k1;
+    const int nfar = (na - g.k0) + (g.k1 - nb);
+    if (nfar > 0 && nb > na && wl::conv_tile_ok(g, per, 2 * nfar)) {                  // (half the NoBody size gate: the launch replaces a much slower kernel)
+      BdimArgs bt{u0, mu0, u_out, dt, pre, post, (post != 1.f) ? 1 : 0, 1, {1.f, 1.f, 1.f}};
+      if (na > g.k0) WL_TRY(wl::conv_tile(u_adv, g, nu, scheme, g.k0, na, &bt, s));
+      if (g.k1 > nb) WL_TRY(wl::conv_tile(u_adv, g, nu, scheme, nb, g.k1, &bt, s));
+      return conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd, na, nb);
+    }
+  }
   return g.D == 3 ? conv_diff_launch<3>(f, u_adv, Phi, g, nu, per, scheme, s, &bd) : conv_diff_launch<2>(f, u_adv, Phi, g, nu, per, scheme, s, &bd);
+}
+// first / last plane (inclusive) on which any workgroup is near the body, keeps f or loads μ₀; host-synchronising (measure!/update! time only)
+int body_masks_planes(const unsigned char* near, const unsigned char* needf, const unsigned char* m0var, const GridX& g, int* dz, hipStream_t s) {
+  const int nbm = body_masks_nbm(g);
+  const size_t n = (size_t)nbm * g.nz;
+  std::vector<unsigned char> h(3 * n);
+  WL_HIP(hipMemcpyAsync(h.data(), near, n, hipMemcpyDeviceToHost, s));
+  WL_HIP(hipMemcpyAsync(h.data() + n, needf, n, hipMemcpyDeviceToHost, s));
+  WL_HIP(hipMemcpyAsync(h.data() + 2 * n, m0var, n, hipMemcpyDeviceToHost, s));
+  WL_HIP(hipStreamSynchronize(s));
+  dz[0] = g.nz; dz[1] = -1;
+  for (int k = 0; k < g.nz; k++) {
+    bool any = false;
+    for (int b = 0; b < nbm && !any; b++) any = h[(size_t)k * nbm + b] || h[n + (size_t)k * nbm + b] || h[2 * n + (size_t)k * nbm + b];
+    if (any) { if (k < dz[0]) dz[0] = k; if (k > dz[1]) dz[1] = k; }
+  }
+  return 0;
 }
 int body_masks_nbm(const GridX& g) { return 8 * wl_strip_blocks(g); }
 int body_masks(unsigned char* near, unsigned char* needf, unsigned char* m0var, const float* V, const float* mu1, const float* mu0, const GridX& g, hipStream_t s) {

@@ -345,6 +345,7 @@ struct wl_sim {
   // body-aware conv_diff!+BDIM! (k_conv_diff<…,FUSE=2>): near / needf masks per (plane, in-plane workgroup)
   unsigned char *mnear = nullptr, *mneedf = nullptr, *mm0var = nullptr;
   int near_box[4] = {0, -1, 0, -1};   // {b0,b1,k0,k1}: bounding box of the near workgroups
+  int dirty_z[2] = {0, -1};           // first / last plane with any near / f-keeping / μ₀-loading workgroup (the other planes are NoBody planes)
   bool use_hybrid = true;
   bool hybrid_ok() const { return d.has_body && use_hybrid && mask_valid && mnear && us && !comm && !forcing && !d.exitBC; }
   int refresh_body_mask(hipStream_t s) {
@@ -354,13 +355,14 @@ struct wl_sim {
     mask_valid = true;
     WL_TRY(wl::body_masks(mnear, mneedf, mm0var, V, mu1, mu0, G, s));
     WL_TRY(wl::body_masks_box(mnear, G, near_box, s));
+    WL_TRY(wl::body_masks_planes(mnear, mneedf, mm0var, G, dirty_z, s));
     return wl::body_mask(farmask, V, mu1, G, s);
   }
   // conv_diff!(f,uadv) + BDIM! with a body: fused NoBody form far from the body, two-pass BDIM! on the near workgroups only
   int conv_bdim_body(const float* uadv, float* uout, float pre, float post, hipStream_t s) {
     WL_TRY(sync_u(s));
     { ProfScope pc(WL_PROF_CONVDIFF, s);
-      WL_TRY(wl::conv_diff_bdim_body(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, mnear, mneedf, mm0var, wl::body_masks_nbm(G), store_f ? 1 : 0, s)); }
+      WL_TRY(wl::conv_diff_bdim_body(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, mnear, mneedf, mm0var, wl::body_masks_nbm(G), store_f ? 1 : 0, s, dirty_z[0], dirty_z[1])); }
     ProfScope pb(WL_PROF_BDIM, s);
     return wl::bdim_near(uout, u, u0, f, V, mu0, mu1, G, dt.back(), pre, post, mnear, wl::body_masks_nbm(G), near_box, s);
   }
@@ -633,6 +635,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
   if (n == "tail_lds") { wl::tail_lds_enable(value); return 0; }
   if (n == "xdefer") { s->mg->use_xdefer = value != 0; return 0; }
+  if (n == "body_tile") { wl::conv_body_tile_enable(value); return 0; }
   if (n == "skip_fill") { s->mg->skip_fill = value != 0; return 0; }
   if (n == "defer_shift") { s->mg->defer_shift = value != 0; return 0; }
   if (n == "zsplit") {   // 0 off, 1 default size gate, 2 levels of any size, v >= 4: levels of at least v·2^20 cells (takes effect at the next update!)
