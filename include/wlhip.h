@@ -194,7 +194,7 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[8 Mi cells] size gate (tests: 0)
-   "convt_min"[8192] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0) */
+   "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0) */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
    g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).

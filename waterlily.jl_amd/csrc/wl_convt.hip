@@ -79,7 +79,7 @@ __device__ __forceinline__ float ct_flux(float U, float a, float b, float c, flo
 
 int g_convt_on = 1;
 int g_convt_chunk = 0;   // 0 = automatic
-long g_convt_min = 8192;  // tile-planes below which the launch cannot fill the chip (tests lower it to drive the kernel on small boxes)
+long g_convt_min = 2048;  // tile-planes below which the gather kernel is at least as fast (128³ = 2048: −1 %, 192³: −5 %, tools/conv_gate.sh; tests set 0 to drive the kernel on small boxes)
 
 // FULL: every tile lies inside the array with all its cells interior ((nx−2) % 64 == 0, (ny−2) % 16 == 0): centre loads/stores unmasked.
 // U0ADV: u⁰ is the advecting field itself (predictor): its value is the plane's centre, no extra load.
