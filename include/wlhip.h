@@ -141,7 +141,8 @@ int wl_mg_smoother_kind(const wl_mg* mg, int level);   /* how smooth! runs on th
                                                           3 z-split (pair kernels away from the body, general blocked kernels near it) */
 int wl_mg_set_fused(wl_mg* mg, int on);   /* bit0 (default 1): temporally blocked smoother on eligible levels, 0: one kernel per pass;
                                              bit1: do not store the final ϵ (scratch of the reference that nothing reads again);
-                                             bit2: no pair kernels; bit3: no single-launch coarse tail; bit4: no z-split on body levels */
+                                             bit2: no pair kernels; bit3: no single-launch coarse tail; bit4: no z-split on body levels;
+                                             bit5: coarse tail in global memory instead of LDS; bit6: x increment of the prolongation not deferred to kernel B */
 /* solver!(ml;tol,itmx): returns iterations in *host_n and the last L₁/L∞; appends to the n history. */
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, void* stream);
 int wl_mg_history(const wl_mg* mg, int16_t* host_out, int cap);                        /* pois.n :66 */
@@ -194,7 +195,10 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[8 Mi cells] size gate (tests: 0)
-   "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0) */
+   "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0)
+   "xdefer"[1] pair smoother: the V-cycle's x += ω·x_c↓ is applied by kernel B together with its own increment (x makes one round trip per smooth!)
+   "tail_lds"[1] the single-launch coarse tail keeps r, x, ϵ of its levels in LDS (0: in global memory)
+   "body_tile"[1] with a body: conv_diff!+BDIM! on the body-free plane ranges through the tiled NoBody kernel ("convt") */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
    g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).
