@@ -21,8 +21,9 @@ int wl_ctx_ensure() {
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { wl_set_error("libwlhip: no HIP device visible — the HIP path has no CPU fallback"); return WL_ENOGPU; }
   WL_HIP(hipGetDevice(&c.device));
   WL_HIP(hipMalloc(&c.red, wl_red_bytes()));
-  WL_HIP(hipHostMalloc((void**)&c.h_d, 8 * sizeof(double), hipHostMallocDefault));
-  WL_HIP(hipHostMalloc((void**)&c.h_f, 8 * sizeof(float), hipHostMallocDefault));
+  // one pinned 128-byte record, laid out like RedWs' device record (8 doubles, then floats): both halves come back in ONE copy
+  WL_HIP(hipHostMalloc((void**)&c.h_d, 128, hipHostMallocDefault));
+  c.h_f = (float*)((char*)c.h_d + 64);
   c.inited = true;
   return 0;
 }

@@ -592,8 +592,12 @@ std::mutex& wl_read_mutex() { static std::mutex m; return m; }
 int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s) {
   std::lock_guard<std::mutex> lock(wl_read_mutex());
   WlCtx& c = wl_ctx();
-  if (nd > 0) WL_HIP(hipMemcpyAsync(c.h_d, ws.res_d, sizeof(double) * (size_t)nd, hipMemcpyDeviceToHost, s));
-  if (nf > 0) WL_HIP(hipMemcpyAsync(c.h_f, ws.res_f, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost, s));
+  if (nd > 0 && nf > 0 && (const char*)ws.res_f == (const char*)ws.res_d + 64 && nd <= 8 && nf <= 16) {
+    WL_HIP(hipMemcpyAsync(c.h_d, ws.res_d, 64 + sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost, s));      // one blit instead of two (≈5 µs each)
+  } else {
+    if (nd > 0) WL_HIP(hipMemcpyAsync(c.h_d, ws.res_d, sizeof(double) * (size_t)nd, hipMemcpyDeviceToHost, s));
+    if (nf > 0) WL_HIP(hipMemcpyAsync(c.h_f, ws.res_f, sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost, s));
+  }
   WL_HIP(hipStreamSynchronize(s));
   for (int q = 0; q < nd; q++) hd[q] = c.h_d[q];
   for (int q = 0; q < nf; q++) hf[q] = c.h_f[q];

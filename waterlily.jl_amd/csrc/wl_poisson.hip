@@ -747,36 +747,140 @@ __device__ __forceinline__ void tail_inside_l(const GridX& g, const TailLds& q, 
     fn(i, j, k, i + j * sy + k * sz);
   }
 }
-template <bool CL>
-__device__ __forceinline__ void tail_smooth_l(const TailLevel& v, const TailLds& q, float* __restrict__ sm, const float* __restrict__ tb, float w) {
+// The cells a thread owns on a level (cell c = threadIdx.x + u·1024, u < Q) with everything that does not change between the phases of one
+// visit of the level — offsets, colour, quirk Q4, and the eight coefficients — evaluated once and kept in registers: the phases are then
+// 7 LDS reads and ≈12 flops per cell (the first version re-derived indices and coefficients in every phase and was bound by that: 40 µs).
+template <int Q> struct TailCells { int o[Q]; int flag[Q]; TailCoef t[Q]; };   // flag: bit 0 = (i+j+k+3)&1, bit 1 = Q4 leaves the plane unswept; o < 0: no cell
+template <bool CL, int Q>
+__device__ __forceinline__ void tail_cells(const TailLevel& v, const TailLds& q, const float* __restrict__ tb, TailCells<Q>& c) {
+  const GridX& g = v.g;
+  const int nxi = g.nx - 2, nyi = g.ny - 2, nzi = g.nz - 2;
+  const int n = nxi * nyi * nzi, sy = (int)g.sy, sz = (int)g.sz;
+#pragma unroll
+  for (int u = 0; u < Q; u++) {
+    const int cc = (int)threadIdx.x + u * 1024;
+    c.o[u] = -1; c.flag[u] = 0;
+    c.t[u] = TailCoef{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cc < n) {
+      // cc < 8192, extents < 8192: (cc+½)·(1/n) lies ≥ 1/(2n) away from an integer, the Float32 error is ≤ 1e-3 ⇒ the truncation is exact
+      const int t = (int)(((float)cc + 0.5f) * q.inx), i = 1 + cc - t * nxi;
+      const int kk = (int)(((float)t + 0.5f) * q.iny), j = 1 + t - kk * nyi, k = 1 + kk;
+      const int o = i + j * sy + k * sz;
+      c.o[u] = o;
+      c.flag[u] = ((i + j + k + 3) & 1) | ((k + 1 > 2 * (g.gnz / 2) - 1) ? 2 : 0);
+      c.t[u] = tail_coef<CL>(v, q, tb, i, j, k, o);
+    }
+  }
+}
+// GaussSeidelRB!(it=4,ω) on the level   src/Poisson.jl:141-148
+template <int Q>
+__device__ __forceinline__ void tail_smooth_q(const TailLevel& v, const TailLds& q, float* __restrict__ sm, const TailCells<Q>& c, float w) {
   const GridX& g = v.g;
   const int cs = (int)g.cs, sy = (int)g.sy, sz = (int)g.sz;
   float* R = sm + q.lo; float* X = R + cs; float* E = X + cs;
-  tail_inside_l(g, q, [&](int i, int j, int k, int o) { E[o] = R[o] * tail_coef<CL>(v, q, tb, i, j, k, o).id; });
+#pragma unroll
+  for (int u = 0; u < Q; u++) if (c.o[u] >= 0) E[c.o[u]] = R[c.o[u]] * c.t[u].id;
   __syncthreads();
   for (int kk0 = 1; kk0 <= 4; kk0++) {
-    tail_inside_l(g, q, [&](int i, int j, int k, int o) {
-      if (((i + j + k + 3 + kk0) & 1) == 0) return;
-      if (k + 1 > 2 * (g.gnz / 2) - 1) return;                                  // quirk Q4
-      const TailCoef t = tail_coef<CL>(v, q, tb, i, j, k, o);
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+      const int o = c.o[u];
+      if (o < 0 || (((c.flag[u] & 1) + kk0) & 1) == 0 || (c.flag[u] & 2)) continue;       // colour of the sweep; quirk Q4
+      const TailCoef& t = c.t[u];
       float s = R[o];
       s -= (E[o - 1] * t.lx + E[o + 1] * t.lxp);
       s -= (E[o - sy] * t.ly + E[o + sy] * t.lyp);
       s -= (E[o - sz] * t.lz + E[o + sz] * t.lzp);
       E[o] = s * t.id;
-    });
+    }
     __syncthreads();
   }
-  tail_inside_l(g, q, [&](int i, int j, int k, int o) {
-    const TailCoef t = tail_coef<CL>(v, q, tb, i, j, k, o);
+#pragma unroll
+  for (int u = 0; u < Q; u++) {
+    const int o = c.o[u];
+    if (o < 0) continue;
+    const TailCoef& t = c.t[u];
     float s = E[o] * t.d;
     s += (E[o - 1] * t.lx + E[o + 1] * t.lxp);
     s += (E[o - sy] * t.ly + E[o + sy] * t.lyp);
     s += (E[o - sz] * t.lz + E[o + sz] * t.lzp);
     R[o] = R[o] - w * s;
     X[o] = X[o] + w * E[o];
+  }
+  __syncthreads();
+}
+// down: Jacobi!(fine); restrict!(coarse.r, fine.r); coarse.x = 0            src/MultiLevelPoisson.jl:92-95
+template <bool CL, int Q>
+__device__ __forceinline__ void tail_down(const TailLevel& f, const TailLevel& c, const TailLds& qf, const TailLds& qc, float* __restrict__ sm, const float* __restrict__ tl) {
+  TailCells<Q> cl;
+  tail_cells<CL, Q>(f, qf, tl, cl);
+  const int fcs = (int)f.g.cs, fsy = (int)f.g.sy, fsz = (int)f.g.sz, ccs = (int)c.g.cs;
+  float* R = sm + qf.lo; float* X = R + fcs; float* E = X + fcs;
+  float* Rc = sm + qc.lo; float* Xc = Rc + ccs;
+#pragma unroll
+  for (int u = 0; u < Q; u++) if (cl.o[u] >= 0) E[cl.o[u]] = R[cl.o[u]] * cl.t[u].id;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < Q; u++) {
+    const int o = cl.o[u];
+    if (o < 0) continue;
+    const TailCoef& t = cl.t[u];
+    float s = E[o] * t.d;
+    s += (E[o - 1] * t.lx + E[o + 1] * t.lxp);
+    s += (E[o - fsy] * t.ly + E[o + fsy] * t.lyp);
+    s += (E[o - fsz] * t.lz + E[o + fsz] * t.lzp);
+    R[o] = R[o] - 1.f * s;
+    X[o] = X[o] + 1.f * E[o];
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < ccs; o += 1024) Xc[o] = 0.f;
+  tail_inside_l(c.g, qc, [&](int i, int j, int k, int o) {
+    const int fi = f.cx ? 2 * i - 1 : i, fj = f.cy ? 2 * j - 1 : j, fk = f.cz ? 2 * k - 1 : k;
+    float s = 0.f;
+    for (int cc = 0; cc <= f.cz; cc++)
+      for (int bb = 0; bb <= f.cy; bb++)
+        for (int aa = 0; aa <= f.cx; aa++) s += R[(fi + aa) + (fj + bb) * fsy + (fk + cc) * fsz];
+    Rc[o] = s;
   });
   __syncthreads();
+}
+// up: [prolongate!+increment!(v;ω) from the level below;] smooth!(v)            :96-100
+template <bool CL, int Q>
+__device__ __forceinline__ void tail_up(const TailLevel& v, const TailLevel& c, bool has_c, const TailLds& qv, const TailLds& qc, float* __restrict__ sm, const float* __restrict__ tl, float w) {
+  TailCells<Q> cl;
+  tail_cells<CL, Q>(v, qv, tl, cl);
+  if (has_c) {
+    const int cs = (int)v.g.cs, csy = (int)c.g.sy, csz = (int)c.g.sz;
+    float* R = sm + qv.lo; float* X = R + cs;
+    const float* Xc = sm + qc.lo + (int)c.g.cs;
+#pragma unroll
+    for (int u = 0; u < Q; u++) {
+      const int o = cl.o[u];
+      if (o < 0) continue;
+      const TailCoef& t = cl.t[u];
+      const int cc = (int)threadIdx.x + u * 1024, nxi = v.g.nx - 2, nyi = v.g.ny - 2;           // (i,j,k) of the cell, as in tail_cells
+      const int tq = (int)(((float)cc + 0.5f) * qv.inx), i = 1 + cc - tq * nxi;
+      const int kq = (int)(((float)tq + 0.5f) * qv.iny), j = 1 + tq - kq * nyi, k = 1 + kq;
+      // down(I) of wl down_off (0-based (i+1)/2 in a coarsened direction); gk = 0 on tail levels
+      auto E = [&](int ii, int jj, int kk) -> float {
+        const int ci = v.cx ? (ii + 1) / 2 : ii, cj = v.cy ? (jj + 1) / 2 : jj, ck = v.cz ? (kk + 1) / 2 : kk;
+        return Xc[ci + cj * csy + ck * csz];
+      };
+      const float e0 = E(i, j, k);
+      float s = e0 * t.d;
+      s += (E(i - 1, j, k) * t.lx + E(i + 1, j, k) * t.lxp);
+      s += (E(i, j - 1, k) * t.ly + E(i, j + 1, k) * t.lyp);
+      s += (E(i, j, k - 1) * t.lz + E(i, j, k + 1) * t.lzp);
+      R[o] = R[o] - w * s;
+      X[o] = X[o] + w * e0;
+    }
+    __syncthreads();
+  }
+  tail_smooth_q<Q>(v, qv, sm, cl, w);
+}
+__device__ __forceinline__ int tail_qsel(const GridX& g) {     // cells per thread of a level, rounded up to 1, 2 or 4 (8 never occurs: see vcycle_tail)
+  const int n = (g.nx - 2) * (g.ny - 2) * (g.nz - 2), q = (n + 1023) >> 10;
+  return q <= 1 ? 1 : (q <= 2 ? 2 : (q <= 4 ? 4 : 8));
 }
 template <bool CL>
 __global__ void __launch_bounds__(1024) k_vcycle_tail_lds(TailArgsL b) {
@@ -795,64 +899,25 @@ __global__ void __launch_bounds__(1024) k_vcycle_tail_lds(TailArgsL b) {
     for (int o = threadIdx.x; o < cs; o += 1024) { R[o] = v.r[o]; R[cs + o] = v.x[o]; R[2 * cs + o] = v.eps[o]; }
   }
   __syncthreads();
-  // ---- down: Jacobi!(fine); restrict!(coarse.r, fine.r); coarse.x = 0            src/MultiLevelPoisson.jl:92-95
   for (int l = 0; l + 1 < a.n; l++) {
     const TailLevel& f = a.lv[l]; const TailLevel& c = a.lv[l + 1];
-    const int fcs = (int)f.g.cs, fsy = (int)f.g.sy, fsz = (int)f.g.sz, ccs = (int)c.g.cs;
-    float* R = sm + b.q[l].lo; float* X = R + fcs; float* E = X + fcs;
-    float* Rc = sm + b.q[l + 1].lo; float* Xc = Rc + ccs;
     const float* tl = tb + 54 * l;
-    tail_inside_l(f.g, b.q[l], [&](int i, int j, int k, int o) { E[o] = R[o] * tail_coef<CL>(f, b.q[l], tl, i, j, k, o).id; });
-    __syncthreads();
-    tail_inside_l(f.g, b.q[l], [&](int i, int j, int k, int o) {
-      const TailCoef t = tail_coef<CL>(f, b.q[l], tl, i, j, k, o);
-      float s = E[o] * t.d;
-      s += (E[o - 1] * t.lx + E[o + 1] * t.lxp);
-      s += (E[o - fsy] * t.ly + E[o + fsy] * t.lyp);
-      s += (E[o - fsz] * t.lz + E[o + fsz] * t.lzp);
-      R[o] = R[o] - 1.f * s;
-      X[o] = X[o] + 1.f * E[o];
-    });
-    __syncthreads();
-    for (int o = threadIdx.x; o < ccs; o += 1024) Xc[o] = 0.f;
-    tail_inside_l(c.g, b.q[l + 1], [&](int i, int j, int k, int o) {
-      const int fi = f.cx ? 2 * i - 1 : i, fj = f.cy ? 2 * j - 1 : j, fk = f.cz ? 2 * k - 1 : k;
-      float s = 0.f;
-      for (int cc = 0; cc <= f.cz; cc++)
-        for (int bb = 0; bb <= f.cy; bb++)
-          for (int aa = 0; aa <= f.cx; aa++) s += R[(fi + aa) + (fj + bb) * fsy + (fk + cc) * fsz];
-      Rc[o] = s;
-    });
-    __syncthreads();
+    switch (tail_qsel(f.g)) {
+      case 1: tail_down<CL, 1>(f, c, b.q[l], b.q[l + 1], sm, tl); break;
+      case 2: tail_down<CL, 2>(f, c, b.q[l], b.q[l + 1], sm, tl); break;
+      default: tail_down<CL, 4>(f, c, b.q[l], b.q[l + 1], sm, tl); break;   // (the launcher admits at most 4096 interior cells per level)
+    }
   }
-  // ---- bottom and up: smooth!(coarse) ; prolongate!+increment!(fine;ω) ; ... ; smooth!(first level)            :96-100
   for (int l = a.n - 1; l >= 0; l--) {
     const TailLevel& v = a.lv[l];
+    const bool has_c = l + 1 < a.n;
+    const int lc = has_c ? l + 1 : l;                                           // (kernel arguments are indexed, never pointed to: no private copy)
     const float* tl = tb + 54 * l;
-    if (l + 1 < a.n) {
-      const TailLevel& c = a.lv[l + 1];
-      const GridX& gf = v.g;
-      const int cs = (int)gf.cs, csy = (int)c.g.sy, csz = (int)c.g.sz;
-      float* R = sm + b.q[l].lo; float* X = R + cs;
-      const float* Xc = sm + b.q[l + 1].lo + (int)c.g.cs;
-      tail_inside_l(gf, b.q[l], [&](int i, int j, int k, int o) {
-        const TailCoef t = tail_coef<CL>(v, b.q[l], tl, i, j, k, o);
-        // down(I) of wl down_off (0-based (i+1)/2 in a coarsened direction); gk = 0 on tail levels
-        auto E = [&](int ii, int jj, int kk) -> float {
-          const int ci = v.cx ? (ii + 1) / 2 : ii, cj = v.cy ? (jj + 1) / 2 : jj, ck = v.cz ? (kk + 1) / 2 : kk;
-          return Xc[ci + cj * csy + ck * csz];
-        };
-        const float e0 = E(i, j, k);
-        float s = e0 * t.d;
-        s += (E(i - 1, j, k) * t.lx + E(i + 1, j, k) * t.lxp);
-        s += (E(i, j - 1, k) * t.ly + E(i, j + 1, k) * t.lyp);
-        s += (E(i, j, k - 1) * t.lz + E(i, j, k + 1) * t.lzp);
-        R[o] = R[o] - a.w * s;
-        X[o] = X[o] + a.w * e0;
-      });
-      __syncthreads();
+    switch (tail_qsel(v.g)) {
+      case 1: tail_up<CL, 1>(v, a.lv[lc], has_c, b.q[l], b.q[lc], sm, tl, a.w); break;
+      case 2: tail_up<CL, 2>(v, a.lv[lc], has_c, b.q[l], b.q[lc], sm, tl, a.w); break;
+      default: tail_up<CL, 4>(v, a.lv[lc], has_c, b.q[l], b.q[lc], sm, tl, a.w); break;
     }
-    tail_smooth_l<CL>(v, b.q[l], sm, tl, a.w);
   }
   // ---- write r, x, ϵ of every level back
   for (int l = 0; l < a.n; l++) {
@@ -1107,6 +1172,7 @@ int vcycle_tail(const TailLevelHost* lv, int n, float w, hipStream_t s) {
   for (int l = 0; l < n; l++) {
     const GridX& g = lv[l].g;
     if (g.D != 3 || g.gk != 0 || g.nz != g.gnz || g.nx < 3 || g.ny < 3 || g.nz < 3 || g.cs > WL_TAIL_CELLS) fits = false;
+    if ((long)(g.nx - 2) * (g.ny - 2) * (g.nz - 2) > 4096) fits = false;      // a thread caches the coefficients of at most 4 cells per level (k_vcycle_tail_lds)
     cl = cl && lv[l].cl && lv[l].cl->on;
     b.q[l].lo = (int)lo; b.q[l].inx = 1.f / (float)(g.nx - 2); b.q[l].iny = 1.f / (float)(g.ny - 2);
     for (int c = 0; c < 3; c++) b.q[l].c[c] = (lv[l].cl && lv[l].cl->on) ? lv[l].cl->c[c] : 0.f;
