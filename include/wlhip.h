@@ -262,6 +262,9 @@ int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_se
 /* TEST mode of a ONE-rank communicator: both neighbours are this rank (z-periodic wrap onto itself), so that the transport
  * calls a one-rank run would skip (ncclSend/ncclRecv groups, in-place ncclAllGather, the scalar combine) execute on a one-GPU box */
 int wl_comm_set_loopback(wl_comm* c, int on);
+/* z-periodic domain on z-slabs: the halo exchanges wrap around (rank 0's lower neighbour is the last rank).  wl_sim_create sets it from the
+ * descriptor's perdir mask; callback transports get both neighbours on every rank and must address them modulo the size. */
+int wl_comm_set_periodic(wl_comm* c, int on);
 /* test hooks: the overlapped exchange (begin on the communicator's stream + wait) and the device-side scalar combine
  * (d8/f8: one 128-byte device record, 8 doubles then 8 floats; Σ / max over ranks in place) */
 int wl_comm_halo_async(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* stream);

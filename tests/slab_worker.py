@@ -72,6 +72,30 @@ def main():
         assert st["halo_bytes_sent"] == (1 + 2) * plane * ncomp * nb, st
         comm.destroy()
         print(f"rank {rank}: cpu_halo ok", flush=True)
+    elif mode == "cpu_halo_periodic":
+        # z-periodic domain: the exchange wraps around (rank 0's lower ghost planes are the last rank's top planes and vice versa)
+        comm = slab.CallbackComm(dist, host_buffers=True)
+        check(L.wl_comm_set_periodic(comm.handle, 1))
+        nloc, ncomp = 6, 2
+        gd = (10, 7, 2 + nloc * size)
+        g = slab.slab_grid(gd, rank, size, halo=3)
+        a = np.full((g.nx, g.ny, g.nz, ncomp), -1.0, dtype=np.float32, order="F")
+        val = lambda K, c: (np.arange(g.nx)[:, None] + 100 * np.arange(g.ny)[None, :] + 10000 * K + 1e6 * c).astype(np.float32)
+        wrap = lambda K: (K - 1) % (nloc * size) + 1            # global interior plane a (ghost) plane index is the periodic image of
+        for k in range(g.k0, g.k1):
+            for c in range(ncomp):
+                a[:, :, k, c] = val(g.gk + k, c)
+        for depth in (1, 2, 3):
+            b = a.copy(order="F")
+            check(L.wl_halo_exchange(comm.handle, b.ctypes.data_as(C.c_void_p), C.byref(g), ncomp, depth, None))
+            for c in range(ncomp):
+                for d in range(1, depth + 1):
+                    lo, hi = g.k0 - d, g.k1 + d - 1
+                    assert np.array_equal(b[:, :, lo, c], val(wrap(g.gk + lo), c)), ("lo", rank, depth, d)
+                    assert np.array_equal(b[:, :, hi, c], val(wrap(g.gk + hi), c)), ("hi", rank, depth, d)
+            assert np.array_equal(b[:, :, g.k0:g.k1], a[:, :, g.k0:g.k1])
+        comm.destroy()
+        print(f"rank {rank}: cpu_halo_periodic ok", flush=True)
     elif mode == "gpu_sim":
         torch.cuda.set_device(0)
         dims = tuple(int(v) for v in sys.argv[2].split("x"))
@@ -102,6 +126,44 @@ def main():
         del sim
         comm.destroy()
         print(f"rank {rank}: gpu_sim ok", flush=True)
+    elif mode == "gpu_per":
+        # periodic directions on z-slabs: the periodic TGV (κ = 2π/N) with perdir given as digits ("12": x and y; "123": all three)
+        torch.cuda.set_device(0)
+        dims = tuple(int(v) for v in sys.argv[2].split("x"))
+        steps = int(sys.argv[3])
+        perdir = tuple(int(c) for c in sys.argv[4])
+        comm = slab.CallbackComm(dist)
+        nu = dims[0] / 1600.0
+        sim = slab.SlabSimulation(comm, dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv_periodic", perdir=perdir)
+        ref = w.FusedSimulation(dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv_periodic", perdir=perdir) if rank == 0 else None
+        for s in range(steps):
+            sim.mom_step_()
+            u = sim.gather_field("u", dist)
+            p = sim.gather_field("p", dist)
+            if os.environ.get("WL_PER_DEBUG") and s == 0:
+                m0 = sim.gather_field("mu0", dist)
+                if rank == 0:
+                    print("  mu0_z slab planes 0,1,2,N-2,N-1:", [float(m0[3, 3, k, 2]) for k in (0, 1, 2, -2, -1)], flush=True)
+            if rank == 0:
+                ref.mom_step_()
+                ur, pr = ref.field("u"), ref.field("p")
+                ins = (slice(1, -1),) * 3
+                du, dp = np.abs(u[ins] - ur[ins]).max(), np.abs(p[ins] - pr[ins]).max()
+                print(f"step {s}: max|du|={du:.3e} max|dp|={dp:.3e} n_slab={sim.pois_n[-2:]} n_ref={ref.pois_n[-2:]} dt={sim.dt[-1]:.6f}/{ref.dt[-1]:.6f}", flush=True)
+                if os.environ.get("WL_PER_DEBUG") and s == 0:
+                    m0r = ref.field("mu0")
+                    print("  mu0_z ref planes 0,1,2,N-2,N-1:", [float(m0r[3, 3, k, 2]) for k in (0, 1, 2, -2, -1)], flush=True)
+                    for c in range(3):
+                        prof = np.abs(u[ins][..., c] - ur[ins][..., c]).max(axis=(0, 1))
+                        print(f"  |du_{c}| per interior plane:", " ".join(f"{v:.0e}" for v in prof), flush=True)
+                    print("  |dp| per interior plane:", " ".join(f"{v:.0e}" for v in np.abs(p[ins] - pr[ins]).max(axis=(0, 1))), flush=True)
+                assert sim.pois_n == ref.pois_n
+                assert abs(float(sim.dt[-1]) - float(ref.dt[-1])) <= 1e-6 * float(ref.dt[-1])
+                assert du < 2e-5 and dp < 2e-4, (du, dp)
+        dist.barrier()
+        del sim
+        comm.destroy()
+        print(f"rank {rank}: gpu_per ok", flush=True)
     elif mode == "gpu_exit":
         # convective exit (exitBC!) + immersed sphere on slabs: the x-exit face is shared by all ranks, its means are global
         torch.cuda.set_device(0)

@@ -32,6 +32,18 @@ def test_slab_exit_bc_with_body_matches_single_domain(n, dims):
         assert f"rank {r}: gpu_exit ok" in out
 
 
+@pytest.mark.parametrize("n,dims,per", [(2, "64x32x64", "12"), (2, "64x64x64", "123"), (2, "64x32x64", "3"), (4, "64x64x128", "123"), (3, "48x32x96", "13"),
+                                        (4, "64x32x256", "3")])
+def test_periodic_directions_on_slabs_match_single_domain(n, dims, per):
+    """periodic TGV on z-slabs (periodic z wraps rank P-1 <-> 0): x/y-periodic copies stay local, the z-periodic boundary is a halo
+    exchange that wraps around — but only where the reference calls BC!/perBC!: between two colour sweeps the single domain reads STALE
+    ghost cells at the periodic boundary, so the sweep-to-sweep exchanges do not wrap.  u, p, pois.n and Δt equal the single-domain run."""
+    extra = {"WL_REPLICATE_PLANES": "16"} if dims.endswith("256") else None       # (two distributed levels in the last case)
+    out = run_ranks(n, "gpu_per", dims, "3", per, timeout=600, extra_env=extra)
+    for r in range(n):
+        assert f"rank {r}: gpu_per ok" in out
+
+
 def test_rccl_transport_single_rank():
     out = run_ranks(1, "gpu_rccl1", timeout=600)
     assert "rank 0: gpu_rccl1 ok" in out

@@ -25,6 +25,14 @@ def test_halo_exchange_and_allgather_over_gloo(n):
         assert f"rank {r}: cpu_halo ok" in out
 
 
+@pytest.mark.parametrize("n", [2, 3])
+def test_periodic_wrap_exchange_over_gloo(n):
+    """z-periodic slabs: every rank has both neighbours, addressed modulo the size; with two ranks both are the same process"""
+    out = run_ranks(n, "cpu_halo_periodic")
+    for r in range(n):
+        assert f"rank {r}: cpu_halo_periodic ok" in out
+
+
 def test_slab_planner():
     import waterlily_jl_amd  # noqa: F401
     from waterlily_jl_amd import slab

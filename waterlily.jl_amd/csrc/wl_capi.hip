@@ -52,7 +52,7 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
   WL_HIP(hipMalloc(&red, wl_red_bytes()));
   ws = wl_red_ws(red);
   const bool dist0 = comm && g0.D == 3 && g0.nz != g0.gnz;
-  if (dist0 && ((per >> 2) & 1u)) { wl_set_error("a z-periodic domain cannot be cut into z-slabs this round"); return WL_EINVAL; }
+  if (dist0 && ((per >> 2) & 1u) && !comm->zperiodic) { wl_set_error("z-periodic z-slabs need a communicator in periodic mode (wl_comm_set_periodic)"); return WL_EINVAL; }
   // level 1 aliases the caller's arrays; r,ϵ,D,iD owned                                 src/Poisson.jl:32-38
   std::vector<wl_grid> grids; std::vector<char> isdist; std::vector<wl_grid> views; std::vector<char> hasview;
   grids.push_back(g0); isdist.push_back(dist0); views.push_back(g0); hasview.push_back(0);
@@ -267,9 +267,10 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
   for (int k0 = fuse ? 2 : 1; k0 <= it; k0++) {
     ProfScope pk(l == 0 ? WL_PROF_GS_SWEEP : -1, s);
     WL_TRY(wl::gs_sweep(p.eps, p.r, p.L, p.iD, p.x_, k0, s));
-    WL_TRY(halo(p, p.eps, 1, s));                                                          // neighbour slabs need this colour before the next sweep
+    WL_TRY(halo(p, p.eps, 1, s, 1, false));                                                // neighbour slabs need this colour before the next sweep (no periodic wrap: the reference's ghost cells are stale here)
   }
   WL_TRY(wl::bc_per_scalar(p.eps, p.x_, perdir, s));                                      // perBC!(ϵ) inside increment! :101
+  if (comm && comm->zperiodic) WL_TRY(halo(p, p.eps, 1, s));                              // … across the periodic z boundary too
   return wl::increment(p.r, p.x, p.eps, p.L, p.D, p.x_, w, s);
 }
 // the levels first..end as one launch: "if (first is not the coarsest) Vcycle!(first); smooth!(first)"

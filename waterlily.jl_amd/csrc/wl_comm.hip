@@ -75,7 +75,7 @@ struct RcclComm : wl_comm {
   int sendrecv_body(ncclComm_t cm, const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) {
     // neighbours: lo = rank-1, hi = rank+1 (loopback: both are this rank — what it sends down comes back as its upper ghost planes and
     // vice versa, the z-periodic wrap; sends and receives to one peer match in issue order, hence lo-send / hi-recv first)
-    const int plo = loopback ? rank : rank - 1, phi = loopback ? rank : rank + 1;
+    const int plo = loopback ? rank : (zperiodic ? (rank + size - 1) % size : rank - 1), phi = loopback ? rank : (zperiodic ? (rank + 1) % size : rank + 1);
     if (slo) WL_NCCL(rccl().Send(slo, bytes, ncclChar, plo, cm, s));
     if (rhi) WL_NCCL(rccl().Recv(rhi, bytes, ncclChar, phi, cm, s));
     if (shi) WL_NCCL(rccl().Send(shi, bytes, ncclChar, phi, cm, s));
@@ -117,9 +117,10 @@ __global__ void k_combine(const char* __restrict__ gathered, int nranks, double*
 }  // namespace
 
 namespace wl {
-int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s) {
+int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s, bool wrap) {
   if (!c || (c->size == 1 && !c->loopback) || g.D != 3 || g.nz == g.gnz) return 0;   // single domain / replicated level: nothing to exchange
-  const bool has_lo = c->loopback || (g.gk + g.k0 > 1), has_hi = c->loopback || (g.gk + g.k1 < g.gnz - 1);
+  const bool per = c->zperiodic && wrap;
+  const bool has_lo = c->loopback || per || (g.gk + g.k0 > 1), has_hi = c->loopback || per || (g.gk + g.k1 < g.gnz - 1);
   const size_t bytes = (size_t)depth * (size_t)g.sz * sizeof(float);
   if (g.k1 - g.k0 < depth || g.k0 < depth) { wl_set_error("halo deeper than the slab"); return WL_EINVAL; }
   if (c->gdepth == 0) c->n_halo++;     // an exchange inside an open group belongs to the round that opened it
@@ -194,6 +195,7 @@ int wl_comm_rccl_add_async(wl_comm* cc, const char uid[128]) {
   if (e != 0) { c->comm_async = nullptr; wl_set_error(std::string("ncclCommInitRank (async): ") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "error")); return WL_ECOMM; }
   return 0;
 }
+int wl_comm_set_periodic(wl_comm* c, int on) { WL_CHECK(c, "null communicator"); c->zperiodic = on != 0; return 0; }
 int wl_comm_set_loopback(wl_comm* c, int on) { WL_CHECK(c && c->size == 1, "loopback is a one-rank test mode"); c->loopback = on != 0; return 0; }
 int wl_comm_halo_async(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* st) {
   WL_CHECK(g && g->D == 3, "halo exchange needs a 3-D slab grid");

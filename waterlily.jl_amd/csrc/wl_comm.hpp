@@ -4,6 +4,7 @@
 
 struct wl_comm {
   int rank = 0, size = 1;
+  bool zperiodic = false;   // the domain is periodic in z: rank 0's lower neighbour is rank size-1 and vice versa (halo exchanges wrap around)
   bool loopback = false;    // one-rank TEST mode: both neighbours are this rank (exercises the transport calls that size==1 skips)
   void* gather = nullptr;   // device scratch for scalar all-gathers: size * 128 bytes
   virtual ~wl_comm();
@@ -24,7 +25,10 @@ struct wl_comm {
 
 namespace wl {
 // exchange `depth` planes of an ncomp-component field along z with both neighbours
-int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s);
+// wrap: on a z-periodic domain also exchange across the periodic boundary (rank 0 <-> rank size-1).  The reference refreshes periodic ghost cells
+// only where it calls BC!/perBC! — an exchange that stands for such a call wraps; one that merely keeps neighbouring slabs coupled between two
+// colour sweeps (the single domain reads live interior cells there, but STALE ghost cells at the periodic boundary) must not.
+int halo(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t s, bool wrap = true);
 // the same exchange on the communicator's own stream: it starts when everything queued on `compute` so far is done (begin) and
 // `compute` waits for it only where the caller says so (wait) — kernels launched in between overlap with the transfer
 int halo_async_begin(wl_comm* c, float* a, const GridX& g, int ncomp, int depth, hipStream_t compute);

@@ -79,8 +79,12 @@ __global__ void __launch_bounds__(WL_BLOCK, WL_CD_WAVES) k_conv_diff(GridX g, fl
   const bool store = true;
   const int k = (D == 3) ? kfirst + pz : 0;
   const IDX o = (IDX)(m + (long)k * g.sz);
-  const int I[3] = {i + 1, j + 1, (D == 3) ? g.gk + k + 1 : 2};    // Julia (global) indices
-  const int N[3] = {g.nx, g.ny, (D == 3) ? g.gnz : 4};
+  // z-periodic domain on z-slabs: the ghost planes hold the wrapped neighbours' data (halo exchange, 2 deep), so along z every owned plane is an
+  // inner plane — neither wall forms nor wrapped addresses (the values the periodic forms read are exactly the ones in the ghost planes)
+  const bool zfree = PER && D == 3 && ((per >> 2) & 1u) && g.nz != g.gnz;
+  if (zfree) per &= ~4u;
+  const int I[3] = {i + 1, j + 1, (D == 3) ? (zfree ? 3 : g.gk + k + 1) : 2};    // Julia (global) indices
+  const int N[3] = {g.nx, g.ny, (D == 3) ? (zfree ? (1 << 28) : g.gnz) : 4};
   const IDX st[3] = {1, (IDX)g.sy, (IDX)g.sz};
   float out[3];
 #ifdef WL_CD_INNER
@@ -164,17 +168,20 @@ __global__ void k_conv_q1(GridX g, float* __restrict__ Phi, const float* __restr
   if (D == 3) loc[d2] = (int)(q / n1);
   if (d == 2) { const int kl = N[2] - 1 - g.gk; if (kl < 0 || kl >= g.nz) return; loc[2] = kl; } else loc[d] = N[d] - 1;
   const int I[3] = {loc[0] + 1, loc[1] + 1, (D == 3) ? g.gk + loc[2] + 1 : 2};
-  if (D == 3 && d != 2) { const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || I[2] == N[2]; if (!owned) return; }
+  if (D == 3 && d != 2) { const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || (I[2] == N[2] && !(((per >> 2) & 1u) && g.nz != g.gnz)); if (!owned) return; }
   for (int c = 0; c < D; c++) if (I[c] < 2) return;
   const long o = (long)loc[0] + (long)loc[1] * g.sy + (long)loc[2] * g.sz;
   const int a = D - 1;
   const float* __restrict__ f = u + (long)a * g.cs;
+  const bool zfree = D == 3 && ((per >> 2) & 1u) && g.nz != g.gnz;    // z-periodic slabs: along z every owned plane is an inner plane (wrapped halos)
+  if (zfree && d == 2) return;                                        // (no physical ghost plane in z on any rank)
   for (int b = D - 1; b >= 0; b--) {
     const bool pb = (per >> b) & 1u;
-    const bool covered = (I[b] >= 3 && I[b] <= N[b] - 1) || (pb && I[b] == 2);
+    const bool zin = zfree && b == 2;
+    const bool covered = zin || (I[b] >= 3 && I[b] <= N[b] - 1) || (pb && I[b] == 2);
     if (!covered) continue;
     const float* __restrict__ ub = u + (long)b * g.cs;
-    Phi[o] = (I[b] == 2) ? flux_lowerP<SCH>(f, ub, o, st[b], st[a], nu, o + (long)(N[b] - 4) * st[b]) : flux_inner<SCH>(f, ub, o, st[b], st[a], nu);
+    Phi[o] = (I[b] == 2 && !zin) ? flux_lowerP<SCH>(f, ub, o, st[b], st[a], nu, o + (long)(N[b] - 4) * st[b]) : flux_inner<SCH>(f, ub, o, st[b], st[a], nu);
     break;
   }
 }
@@ -435,7 +442,7 @@ __global__ void k_bc_vec(GridX g, float* __restrict__ a_, float U0, float U1, fl
   I[0] = loc[0] + 1; I[1] = loc[1] + 1; I[2] = (D == 3) ? g.gk + loc[2] + 1 : 1;
   if (D == 3 && d != 2) {   // x/y planes: skip halo planes owned by a neighbour rank (filled by the halo exchange)
     const int K = I[2];
-    const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || K == 1 || K == N[2];
+    const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || (zwalls && (K == 1 || K == N[2]));   // (z-periodic slabs: planes 1 and N are halo planes too)
     if (!owned) return;
   }
   const long o = (long)loc[0] + (long)loc[1] * g.sy + (long)loc[2] * g.sz;
@@ -482,7 +489,7 @@ __global__ void k_bc_vec_fn(GridX g, float* __restrict__ a_, const float* __rest
   I[0] = loc[0] + 1; I[1] = loc[1] + 1; I[2] = (D == 3) ? g.gk + loc[2] + 1 : 1;
   if (D == 3 && d != 2) {
     const int K = I[2];
-    const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || K == 1 || K == N[2];
+    const bool owned = (loc[2] >= g.k0 && loc[2] < g.k1) || (zwalls && (K == 1 || K == N[2]));   // (z-periodic slabs: planes 1 and N are halo planes too)
     if (!owned) return;
   }
   auto off = [&](const int* J) -> long { return (long)(J[0] - 1) + (long)(J[1] - 1) * g.sy + ((D == 3) ? (long)(J[2] - 1 - g.gk) * g.sz : 0); };
@@ -654,6 +661,8 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
   // planes: owned planes plus the physical ghost planes held by this rank (single domain: all planes), cut to [ka,kb)
   int kfirst = 0, klast = 1;
   if (D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
+  const bool zfree = D == 3 && ((per >> 2) & 1u) && g.nz != g.gnz;          // z-periodic slabs: no physical ghost planes, the halos are exchanged
+  if (zfree) { kfirst = g.k0; klast = g.k1; }
   if (D == 3) { if (ka > kfirst) kfirst = ka; if (kb < klast) klast = kb; }
   if (!q1) Phi = nullptr;
   if (kfirst >= klast) {

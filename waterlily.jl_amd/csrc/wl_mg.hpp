@@ -43,7 +43,7 @@ struct wl_mg {
   std::vector<double> log_r1, log_rinf, log_w;
 
   int build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, int maxlevels, wl_comm* c = nullptr);
-  int halo(Level& v, float* a, int ncomp, hipStream_t s, int depth = 1) { return v.dist ? wl::halo(comm, a, v.x_, ncomp, depth, s) : 0; }
+  int halo(Level& v, float* a, int ncomp, hipStream_t s, int depth = 1, bool wrap = true) { return v.dist ? wl::halo(comm, a, v.x_, ncomp, depth, s, wrap) : 0; }
   // a distributed level whose smooth! runs as the blocked pair kernels (constant coefficients, 3 ghost planes)
   bool pair_slab(const Level& v) const { return v.dist && v.g.k0 >= 3 && use_fused && !perdir && wl::gsrb_pair_ok(v.x_, v.cl); }
   ~wl_mg();

@@ -548,6 +548,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   WL_TRY(wl_ctx_ensure());
   const bool slab = comm && comm->size > 1;
   wl_sim* s = new wl_sim(); s->d = *desc; s->comm = slab ? comm : nullptr;
+  if (slab && desc->D == 3 && ((desc->perdir_mask >> 2) & 1u)) comm->zperiodic = true;      // the halo exchanges wrap around (rank 0 <-> rank size-1)
   int32_t ng[3] = {desc->dims[0] + 2, desc->dims[1] + 2, desc->D == 3 ? desc->dims[2] + 2 : 1};
   if (slab) {
     if (desc->u || desc->u0 || desc->f || desc->p || desc->sigma || desc->V || desc->mu0 || desc->mu1) { delete s; wl_set_error("slab simulations own their arrays"); return WL_EINVAL; }

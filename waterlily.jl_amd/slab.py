@@ -58,17 +58,20 @@ class CallbackComm:
             torch, dist = self.torch, self.dist
             self._sync(stream)
             reqs, keep = [], []
+            # peers modulo the size (a z-periodic domain wraps around); tag 0: planes travelling down (my lower planes -> the lower neighbour's upper
+            # ghosts), tag 1: planes travelling up — with two ranks both neighbours are the same process and the tags keep the two apart
+            lo, hi = (self.rank - 1) % self.size, (self.rank + 1) % self.size
             if slo:
                 b = np.empty(nbytes, dtype=np.uint8); self._out(b, slo, nbytes); t = torch.from_numpy(b); keep.append(t)
-                reqs.append(dist.isend(t, self.rank - 1, group=self.group))
+                reqs.append(dist.isend(t, lo, group=self.group, tag=0))
             if shi:
                 b = np.empty(nbytes, dtype=np.uint8); self._out(b, shi, nbytes); t = torch.from_numpy(b); keep.append(t)
-                reqs.append(dist.isend(t, self.rank + 1, group=self.group))
+                reqs.append(dist.isend(t, hi, group=self.group, tag=1))
             rl = rh = None
             if rlo:
-                rl = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rl, self.rank - 1, group=self.group))
+                rl = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rl, lo, group=self.group, tag=1))
             if rhi:
-                rh = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rh, self.rank + 1, group=self.group))
+                rh = torch.empty(nbytes, dtype=torch.uint8); reqs.append(dist.irecv(rh, hi, group=self.group, tag=0))
             for r in reqs:
                 r.wait()
             if rl is not None:
@@ -172,7 +175,7 @@ class SlabSimulation:
         g = wl_grid()
         check(lib().wl_sim_grid(h, C.byref(g)))
         self.grid = g
-        check(lib().wl_sim_apply_ic(h, {"uBC": 0, "tgv": 1}[ic], None))
+        check(lib().wl_sim_apply_ic(h, {"uBC": 0, "tgv": 1, "tgv_periodic": 2}[ic], None))
         check(lib().wl_sim_init_flow(h, None))
 
     def __del__(self):
