@@ -50,11 +50,11 @@ static bool rows16(const GridX& g, int kernel = 0) {   // kernel: 1 = A, 2 = B (
   const int force = (kernel == 1 && force_a) ? force_a : ((kernel == 2 && force_b) ? force_b : force_all);
   if (force == 16) return true;
   if (force == 32) return false;
-  // measured: 256³ levels gain (A+B 0.28 -> 0.24 ms), 512³ loses (B 0.72 -> 0.80 ms), 128³ and below lose slightly
+  // measured with the 128-VGPR kernels (tools/rows_gate.sh, tools/rows512.sh): 16-row tiles win on every level below the 512²-plane class
+  // (128³: 0.582 -> 0.555 ms/step, 256³: 1.845 -> 1.811), 32-row tiles on 512² planes (A 0.96 vs 1.01, B 1.41 vs 1.53 ms/step)
   const long tiles32 = (long)((g.nx + 55) / 56) * ((g.ny + 25) / 26);
-  const long rounds32 = tiles32 * ((g.k1 - g.k0 + 31) / 32);
-  // (in-plane size decides first: a 512² plane has 200 tiles of 64×32 cells — enough parallelism per plane layer, also on a z-slab of few planes)
-  return tiles32 >= 24 && tiles32 < 128 && rounds32 >= 128 && rounds32 < 2048;
+  // (the in-plane size decides: a 512² plane has 200 tiles of 64×32 cells — enough parallelism per plane layer, also on a z-slab of few planes)
+  return tiles32 < 128;
 }
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s) {
   return rows16(g, 1) ? pair16::gsrb_pair_A(emid, r, g, cl, s) : pair32::gsrb_pair_A(emid, r, g, cl, s);
