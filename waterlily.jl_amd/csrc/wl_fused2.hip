@@ -35,11 +35,12 @@ int g_pro_fast = 1;   // bit 1 of gsrb_pair_enable: register-window prolongation
 #undef WL_PT_Y
 #undef WL_PNS
 
+static int pair_min_nx() { static const int v = getenv("WL_PAIR_MIN_NX") ? atoi(getenv("WL_PAIR_MIN_NX")) : 34; return v; }   // smallest level width of the pair kernels (34: 256³ 1.81 -> 1.78 ms/step against the one-cell kernels on the 34-wide level; tools/minnx_gate.sh)
 namespace wl {
 void gsrb_pair_enable(int on) { g_pair_on = on & 1; g_pro_fast = (on & 2) == 0; }
 // geometry: even nx (float2), tiles not mostly empty, 32-bit offsets; a z-slab needs 3 ghost planes per side (kernel B's halo)
 bool gsrb_pair_geom_ok(const GridX& g) {
-  return g_pair_on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.gnz >= 10 && (g.k1 - g.k0) >= 8 && (g.nz == g.gnz || g.k0 >= 2) && g.cs < (1L << 30);   // (z-slab: kernel A reads 2 planes below its first output plane, B 3 — wl_mg::pair_slab checks the level's ghost depth)
+  return g_pair_on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= pair_min_nx() && g.ny >= 34 && g.gnz >= 10 && (g.k1 - g.k0) >= 8 && (g.nz == g.gnz || g.k0 >= 2) && g.cs < (1L << 30);   // (z-slab: kernel A reads 2 planes below its first output plane, B 3 — wl_mg::pair_slab checks the level's ghost depth)
 }
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl) { return cl.on && gsrb_pair_geom_ok(g); }
 // 16-row tiles where the 32-row tiling cannot fill the chip for many rounds (WL_PAIR_ROWS=16|32 forces one: experiments)
