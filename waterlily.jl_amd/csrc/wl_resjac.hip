@@ -225,7 +225,22 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
   const int np = g.k1 - g.k0;
   static const int envc = getenv("WL_RJ_CHUNK") ? atoi(getenv("WL_RJ_CHUNK")) : 0;
   int zc = envc;
-  if (zc <= 0) { const int chunks = (3072 + ntiles - 1) / ntiles; zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; }
+  if (zc <= 0) {
+    // equal workgroups run in rounds of 32 CUs × 2 resident workgroups per XCD (tile ranges are dealt XCD by XCD): minimise
+    // rounds × (planes per chunk + the 2 warm-up planes), with a balance penalty for few rounds — as wl_fused2's zchunk2.  The former fixed target of
+    // 3072 workgroups gave 6.2 rounds at 512³, i.e. a seventh, almost empty one.
+    static const int chforce = getenv("WL_RJ_CHUNKS") ? atoi(getenv("WL_RJ_CHUNKS")) : 0;     // experiments: number of chunks
+    double best = -1.0; zc = np;
+    for (int chunks = 1; chunks <= np; chunks++) {
+      const int z = (np + chunks - 1) / chunks;
+      if (z < 8) break;
+      const long W = (long)per * ((np + z - 1) / z), rounds = (W + 63) / 64;
+      double cost = (double)rounds * (z + 2) * (1.0 + 0.3 / (double)rounds);
+      if (W < 64) cost = (z + 2) * 1.3;
+      if (chforce > 0) cost = (chunks == chforce) ? 0.0 : 1e30;
+      if (best < 0 || cost < best) { best = cost; zc = z; }
+    }
+  }
   if (zc > np) zc = np;
   const int nch = (np + zc - 1) / zc;
   const unsigned nb = (unsigned)(8 * per * nch);
