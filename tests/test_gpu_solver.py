@@ -733,6 +733,28 @@ def test_tiled_conv_diff_on_the_body_free_planes_is_bit_identical(w, scheme):
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+def test_ghost_shell_of_p_is_scaled_when_it_is_not_zero(w):
+    """mom_project!'s `x .*= dt` scales ALL cells.  The fused head skips its ghost-shell pass while p's ghost cells are +0 (the state the library itself
+    maintains) — after ghost values were written from outside (set_field) the pass must run: same u, p as the two-kernel path, which scales every cell."""
+    N = 96
+    res = {}
+    rng = np.random.default_rng(5)
+    for tag, rj in (("fused", 1), ("plain", 0)):
+        sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+        sim.set_option("resjac", rj); sim.set_option("resjac_min", 0)
+        sim.mom_step_()
+        p = sim.field("p")
+        g = np.random.default_rng(7).uniform(-1, 1, size=p.shape).astype(np.float32)
+        p[0, :, :] = g[0, :, :]; p[-1, :, :] = g[-1, :, :]; p[:, 0, :] = g[:, 0, :]; p[:, -1, :] = g[:, -1, :]; p[:, :, 0] = g[:, :, 0]; p[:, :, -1] = g[:, :, -1]
+        sim.set_field("p", p)
+        for _ in range(2):
+            sim.mom_step_()
+        res[tag] = (sim.field("u"), sim.field("p"), sim.pois_n)
+    assert res["fused"][2] == res["plain"][2]
+    assert np.array_equal(res["fused"][0], res["plain"][0]) and np.array_equal(res["fused"][1], res["plain"][1])
+    assert np.abs(res["fused"][1][0, 5, 5]) > 0          # the ghost values survived (scaled by dt and back)
+
+
 BODIES_3D = [
     ("cylinder", (11.0, 13.5, 0.0), 4.0, 2),                                   # along z: the circle of the reference's 2-D cases, extruded
     ("cylinder", (0.0, 14.0, 12.5), 3.5, 0),                                   # along x

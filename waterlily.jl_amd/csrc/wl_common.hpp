@@ -255,7 +255,9 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
 // fused head of mom_project! + the V-cycle's first Jacobi! on the finest level (wl_resjac.hip)
 void resjac_enable(int on, long min_cells);
 bool resjac_ok(const GridX& g, const ConstL& cl);
-int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
+int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s,
+           bool shell = true);   // shell = false: x's (and x_out's) ghost cells are known to be +0 — the ghost-shell scaling pass is skipped
+int shell_nonzero(const float* a, const GridX& g, int* dev_flag, hipStream_t s);
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold = nullptr);
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma = 1, const BcFold* fold = nullptr);
 int project_unscale_split(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);

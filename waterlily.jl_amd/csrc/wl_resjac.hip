@@ -193,6 +193,26 @@ __global__ void k_scale_shell(GridX g, float* __restrict__ xout, const float* __
     xout[base + m] = p[base + m] * dt;
   }
 }
+// does the ghost shell of p hold anything but +0?  (then x_out's shell — zero since allocation, rewritten as 0/dt by the projection tails — already IS p·dt
+// and k_scale_shell can be skipped: 0.05 ms per solve at 512³, the strided columns make it slow for its size)
+__global__ void k_shell_nonzero(GridX g, const float* __restrict__ p, int* __restrict__ flag) {
+  const int k = blockIdx.y;
+  const long base = (long)k * g.sz;
+  bool bad = false;
+  if (k == 0 || k == g.nz - 1) {
+    for (long m = (long)blockIdx.x * WL_BLOCK + threadIdx.x; m < g.sz; m += (long)gridDim.x * WL_BLOCK) bad = bad || (__float_as_uint(p[base + m]) != 0u);
+  } else {
+    const long ring = 2L * g.nx + 2L * (g.ny - 2);
+    for (long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x; q < ring; q += (long)gridDim.x * WL_BLOCK) {
+      long m;
+      if (q < g.nx) m = q;
+      else if (q < 2L * g.nx) m = (long)(g.ny - 1) * g.sy + (q - g.nx);
+      else { const long t = q - 2L * g.nx; const long jj = 1 + (t >> 1); m = jj * g.sy + ((t & 1) ? g.nx - 1 : 0); }
+      bad = bad || (__float_as_uint(p[base + m]) != 0u);
+    }
+  }
+  if (bad) atomicOr(flag, 1);
+}
 // Σ of the per-workgroup partials → res_d[0] (Σr), res_d[slot_d] (L₁), res_f[slot_f] (L∞)
 __global__ void k_resjac_fin(const double* __restrict__ psum, const double* __restrict__ pl1, const float* __restrict__ pmax, int n, double* __restrict__ res_d, float* __restrict__ res_f,
                              int slot_d, int slot_f) {
@@ -219,7 +239,16 @@ bool resjac_ok(const GridX& g, const ConstL& cl) {
 }
 // z=∇·u; x_out = x·dt (+ω·ϵ on interior cells); r_out = residual after Jacobi!(ω=w); Σr -> res_d[0], L₁(r) -> res_d[slot_d], L∞(r) -> res_f[slot_f]
 // (the norms of the residual BEFORE Jacobi!, as solver! logs them).  x_out ≠ x, r_out's ghost cells are left untouched (zero).
-int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s) {
+// 1: some ghost cell of a (3-D single-domain array) is not +0, 0: all are; host-synchronising (called when the array may have been written from outside)
+int shell_nonzero(const float* a, const GridX& g, int* dev_flag, hipStream_t s) {
+  WL_HIP(hipMemsetAsync(dev_flag, 0, sizeof(int), s));
+  hipLaunchKernelGGL(k_shell_nonzero, dim3(8, (unsigned)g.nz), dim3(WL_BLOCK), 0, s, g, a, dev_flag);
+  int h = 1;
+  WL_HIP(hipMemcpyAsync(&h, dev_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  WL_HIP(hipStreamSynchronize(s));
+  return h ? 1 : 0;
+}
+int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s, bool shell) {
   if (xout == x) { wl_set_error("resjac: output aliases input"); return WL_EINVAL; }
   const int ntiles = ((g.nx - 1 + RJ_CX - 1) / RJ_CX) * ((g.ny - 2 + RJ_CY - 1) / RJ_CY), per = (ntiles + 7) >> 3;
   const int np = g.k1 - g.k0;
@@ -245,7 +274,7 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
   const int nch = (np + zc - 1) / zc;
   const unsigned nb = (unsigned)(8 * per * nch);
   if (nb > WL_MAXPART) { wl_set_error("resjac: too many workgroups for the reduction workspace"); return WL_EINVAL; }
-  hipLaunchKernelGGL(k_scale_shell, dim3(8, (unsigned)g.nz), dim3(WL_BLOCK), 0, s, g, xout, x, dt);
+  if (shell) hipLaunchKernelGGL(k_scale_shell, dim3(8, (unsigned)g.nz), dim3(WL_BLOCK), 0, s, g, xout, x, dt);
   hipLaunchKernelGGL(k_resjac, dim3(nb), dim3(RJ_N), 0, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm);
   hipLaunchKernelGGL(k_resjac_fin, dim3(1), dim3(WL_BLOCK), 0, s, (const double*)ws.pa, (const double*)ws.pb, (const float*)ws.pm, (int)nb, ws.res_d, ws.res_f, slot_d, slot_f);
   WL_LAUNCH_CHECK(); return 0;

@@ -421,6 +421,7 @@ struct wl_sim {
   bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
   bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
   long n_resjac = 0, n_resjac_redo = 0;   // how often the fused head stood / had to be redone because the mean shift was due
+  int p_shell = -1;          // ghost shell of p / the spare pressure array: -1 unknown (check before the next fused head), 0 all +0, 1 something else, 2 caller-owned p (never assumed)
   bool use_fuse_cfl = true;  // the corrector's projection tail also produces CFL's σ and max(σ)
   bool cfl_done = false;
   int project(float w, hipStream_t s, bool with_cfl = false) {                           // mom_project! :223-232
@@ -435,7 +436,9 @@ struct wl_sim {
       if (use_resjac && !store_f && !comm && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl)) {
         // head + the V-cycle's first Jacobi!(fine) in one launch, assuming residual!'s mean shift is not due (wl_resjac.hip); Σr decides
         { ProfScope pr(WL_PROF_RESIDUAL, s);
-          WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s)); }
+          // p's and the spare's ghost cells are +0 unless someone wrote them from outside (checked once after a pointer to p was handed out): no shell pass then
+          if (p_shell < 0) p_shell = (wl::shell_nonzero(p, G, (int*)(mg->ws.res_f + 7), s) || wl::shell_nonzero(ps, G, (int*)(mg->ws.res_f + 7), s)) ? 1 : 0;
+          WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s, p_shell != 0)); }
         double sr; WL_TRY(wl::read_results(mg->ws, &sr, 1, nullptr, 0, s));
         const float sm = (float)sr / (float)(double)wl_ninside_global(mg->lv[0].g);
         if (std::fabs(sm) <= 2.f * 1.1920929e-7f && !resjac_force_redo) {                                       // src/Poisson.jl:96: no shift — the fused results stand
@@ -578,6 +581,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   else if (desc->us && (none || all3) && !desc->exitBC) s->us = desc->us;   // caller-owned spare: the roles of {u,u0,us} rotate (wlhip.h)
   s->ps = pcur; pcur += nc;
   s->dt.assign(1, desc->dt0);
+  if (desc->p) s->p_shell = 2;     // a caller-owned p can be written behind the library's back: its ghost shell is always scaled
   s->swap_ok = (none || all3) && !desc->exitBC;
   // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
   if (!desc->mu0) {
@@ -607,7 +611,7 @@ float* wl_sim_field(wl_sim* s, const char* name) {
   const std::string n(name);
   (void)s->sync_u(0);        // the caller is about to read or write the arrays: finish an exchange that is still in flight
   if (n == "V" || n == "mu1" || n == "mu0") s->mask_valid = false;
-  if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") return s->p;
+  if (n == "u") return s->u; if (n == "u0") return s->u0; if (n == "f") return s->f; if (n == "p") { if (s->p_shell != 2) s->p_shell = -1; return s->p; }
   if (n == "sigma") return s->sigma; if (n == "V") return s->V; if (n == "mu0") return s->mu0; if (n == "mu1") return s->mu1;
   if (n == "us") return s->us;
   return nullptr;
