@@ -164,6 +164,35 @@ def main():
         del sim
         comm.destroy()
         print(f"rank {rank}: gpu_per ok", flush=True)
+    elif mode == "gpu_per_body":
+        # immersed sphere in a stream along x, periodic in y and z, on z-slabs (the sphere sits on a slab boundary: μ₁, V and f cross it; the
+        # z-periodic wrap carries the wake's images)
+        torch.cuda.set_device(0)
+        dims = tuple(int(v) for v in sys.argv[2].split("x"))
+        steps = int(sys.argv[3])
+        comm = slab.CallbackComm(dist)
+        R, c = dims[1] / 8.0, (dims[0] / 4.0, dims[1] / 2.0 - 1, dims[2] / 2.0 - 1)
+        nu = 2 * R / 250.0
+        sim = slab.SlabSimulation(comm, dims, (1.0, 0.0, 0.0), 2 * R, U=1, nu=nu, has_body=True, perdir=(2, 3))
+        sim.measure_sphere_(c, R)
+        ref = None
+        if rank == 0:
+            ref = w.FusedSimulation(dims, (1.0, 0.0, 0.0), 2 * R, U=1, nu=nu, has_body=True, perdir=(2, 3))
+            ref.measure_sphere_(c, R)
+        for s in range(steps):
+            sim.mom_step_()
+            u = sim.gather_field("u", dist)
+            if rank == 0:
+                ref.mom_step_()
+                ins = (slice(1, -1),) * 3
+                du = np.abs(u[ins] - ref.field("u")[ins]).max()
+                print(f"step {s}: max|du|={du:.3e} n_slab={sim.pois_n[-2:]} n_ref={ref.pois_n[-2:]} dt={sim.dt[-1]:.6f}/{ref.dt[-1]:.6f}", flush=True)
+                assert sim.pois_n == ref.pois_n
+                assert du < 5e-5, du
+        dist.barrier()
+        del sim
+        comm.destroy()
+        print(f"rank {rank}: gpu_per_body ok", flush=True)
     elif mode == "gpu_exit":
         # convective exit (exitBC!) + immersed sphere on slabs: the x-exit face is shared by all ranks, its means are global
         torch.cuda.set_device(0)

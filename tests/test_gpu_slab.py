@@ -44,6 +44,13 @@ def test_periodic_directions_on_slabs_match_single_domain(n, dims, per):
         assert f"rank {r}: gpu_per ok" in out
 
 
+@pytest.mark.parametrize("n,dims", [(2, "64x32x32"), (4, "48x32x64")])
+def test_body_in_a_z_periodic_stream_on_slabs_matches_single_domain(n, dims):
+    out = run_ranks(n, "gpu_per_body", dims, "3", timeout=600)
+    for r in range(n):
+        assert f"rank {r}: gpu_per_body ok" in out
+
+
 def test_rccl_transport_single_rank():
     out = run_ranks(1, "gpu_rccl1", timeout=600)
     assert "rank 0: gpu_rccl1 ok" in out
