@@ -227,9 +227,25 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
         // z-slab, ONE exchange round per smooth!: r travels 5 planes deep and kernel A also computes r' and ϵ_mid on the 3 (2) ghost planes
         // kernel B reads, instead of receiving them (x is updated on the owned planes only).  5 planes instead of 2+3+2, one latency
         // instead of two, ≈6 redundant planes of kernel A per rank.
-        WL_TRY(halo(p, p.r, 1, s, 5));
         GridX ge = p.x_; ge.k0 = p.x_.k0 - 3; ge.k1 = p.x_.k1 + 3;
+        if (overlap_smooth && p.x_.k1 - p.x_.k0 >= 16) {
+          // the exchange runs on the communicator's own stream while kernel A computes the planes that need no ghost plane of r (its outputs
+          // [k0+2,k1−2) read r on [k0,k1) only); the two boundary slices (5 planes each, ghost planes included) follow the wait — as conv_diff! does with u
+          WL_TRY(wl::halo_async_begin(comm, p.r, p.x_, 1, 5, s));
+          GridX gi = p.x_; gi.k0 = p.x_.k0 + 2; gi.k1 = p.x_.k1 - 2;
+          GridX glo = p.x_; glo.k0 = ge.k0; glo.k1 = p.x_.k0 + 2;
+          GridX ghi = p.x_; ghi.k0 = p.x_.k1 - 2; ghi.k1 = ge.k1;
+          ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s);
+          bool xd_i = xdef, xd_l = xdef, xd_h = xdef;
+          WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, gi, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1, &xd_i, true));
+          WL_TRY(wl::halo_async_wait(comm, s));
+          WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, glo, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1, &xd_l, true));
+          WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, ghi, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1, &xd_h, true));
+          if (xd_i != xdef || xd_l != xdef || xd_h != xdef) { wl_set_error("smooth!: the slices of kernel A disagree on the deferred x increment"); return WL_EINVAL; }
+        } else {
+        WL_TRY(halo(p, p.r, 1, s, 5));
         { ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s); WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, ge, coarse.x_, w, p.cl, s, p.x_.k0, p.x_.k1, &xdef)); }
+        }
         { ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s); WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, p.x_, w, nws, 2, 1, p.cl, s, xdef ? &xd : nullptr)); }
         norm_slots = 0;
         if (norms_done) *norms_done = want_norms;
@@ -596,7 +612,7 @@ int wl_mg_smoother_kind(const wl_mg* mg, int l) {   // 0 one kernel per pass, 1 
   return wl::gsrb_pair_ok(p.x_, p.cl) ? 2 : 1;
 }
 int wl_mg_level_is_const(const wl_mg* mg, int l) { return (l >= 0 && l < (int)mg->lv.size()) ? mg->lv[(size_t)l].cl.on : 0; }
-int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; wl::tail_lds_enable((on & 32) == 0); mg->use_xdefer = (on & 64) == 0; return 0; }
+int wl_mg_set_fused(wl_mg* mg, int on) { mg->use_fused = (on & 1) != 0; mg->store_eps = (on & 2) == 0; wl::gsrb_pair_enable((on & 4) == 0); mg->use_tail = (on & 8) == 0; mg->use_zsplit = (on & 16) == 0; wl::tail_lds_enable((on & 32) == 0); mg->use_xdefer = (on & 64) == 0; mg->overlap_smooth = (on & 128) == 0; return 0; }
 int wl_mg_vcycle(wl_mg* mg, int l, float w, void* st) { WL_CHECK(l >= 0 && l + 1 < (int)mg->lv.size(), "level out of range"); return mg->vcycle(l, w, wl_stream(st), false); }
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* n, double* r1, float* rinf, void* st) { return mg->solve(tol, itmx <= 0 ? 32 : itmx, n, r1, rinf, wl_stream(st)); }
 int wl_mg_history(const wl_mg* mg, int16_t* out, int cap) { const int n = (int)mg->n.size(); for (int k = 0; k < n && k < cap; k++) out[k] = mg->n[(size_t)k]; return n; }

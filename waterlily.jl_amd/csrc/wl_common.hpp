@@ -284,7 +284,7 @@ int pcg_stage(int stage, float* eps, float* r, float* x, float* z, const float* 
 bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist);
 int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, const ConstL& cl, hipStream_t s);
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
-                     int xk0 = -(1 << 30), int xk1 = 1 << 30, bool* defer_x = nullptr);   // defer_x (in/out): leave `x += ω·x_c↓` to kernel B (cleared if this path cannot)
+                     int xk0 = -(1 << 30), int xk1 = 1 << 30, bool* defer_x = nullptr, bool range = false);   // defer_x (in/out): leave `x += ω·x_c↓` to kernel B (cleared if this path cannot); range: g is a short plane sub-range of a qualifying level
 // The V-cycle's `x += ω·x_c↓` handed from kernel A to kernel B of the same smooth! (pair kernels only): A leaves x alone, B applies both
 // increments of x in order — x is read and written once per smooth! instead of twice.
 struct XDefer { const float* xc; GridX gc; float w; };
@@ -295,6 +295,7 @@ int finalize_sum_max(const RedWs& ws, int nparts, int slot_d, int slot_f, hipStr
 // pair variant of the blocked smoother for constant-coefficient levels (wl_fused2.hip); chosen inside gsrb_fused_* when eligible
 void gsrb_pair_enable(int on);
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl);
+bool gsrb_pair_ok_range(const GridX& g, const ConstL& cl);
 bool gsrb_pair_geom_ok(const GridX& g);
 int gsrb_pair_A(float* emid, const float* r, const GridX& g, const ConstL& cl, hipStream_t s);
 int gsrb_pair_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,

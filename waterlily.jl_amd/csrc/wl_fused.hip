@@ -326,8 +326,8 @@ int gsrb_fused_A(float* emid, const float* r, const float* L, const GridX& g, co
 }
 // prolongate!+increment!(ω) of the V-cycle folded into kernel A: r' -> rnew (≠ r), x updated in place, ϵ_mid from r'
 int gsrb_fused_A_pro(float* emid, float* rnew, float* x, const float* r, const float* xc, const float* L, const GridX& g, const GridX& gc, float w, const ConstL& cl, hipStream_t s,
-                     int xk0, int xk1, bool* defer_x) {
-  if (gsrb_pair_ok(g, cl) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) {
+                     int xk0, int xk1, bool* defer_x, bool range) {
+  if ((range ? gsrb_pair_ok_range(g, cl) : gsrb_pair_ok(g, cl)) && gc.cs < (1L << 30) && al8(emid, rnew, x, r)) {
     if (defer_x && *defer_x) { xk0 = 0; xk1 = 0; }    // x is left to kernel B (wl::XDefer)
     return gsrb_pair_A_pro(emid, rnew, x, r, xc, g, gc, w, cl, s, xk0, xk1);
   }

@@ -43,6 +43,8 @@ bool gsrb_pair_geom_ok(const GridX& g) {
   return g_pair_on && g.D == 3 && (g.nx & 1) == 0 && g.nx >= pair_min_nx() && g.ny >= 34 && g.gnz >= 10 && (g.k1 - g.k0) >= 8 && (g.nz == g.gnz || g.k0 >= 2) && g.cs < (1L << 30);   // (z-slab: kernel A reads 2 planes below its first output plane, B 3 — wl_mg::pair_slab checks the level's ghost depth)
 }
 bool gsrb_pair_ok(const GridX& g, const ConstL& cl) { return cl.on && gsrb_pair_geom_ok(g); }
+// a plane sub-range [g.k0,g.k1) of a level that qualifies as a whole: any number of planes (boundary slices of a slab, ranges of the z-split)
+bool gsrb_pair_ok_range(const GridX& g, const ConstL& cl) { GridX h = g; if (h.k1 - h.k0 < 8) h.k1 = h.k0 + 8; return g.k1 > g.k0 && gsrb_pair_ok(h, cl); }
 // 16-row tiles where the 32-row tiling cannot fill the chip for many rounds (WL_PAIR_ROWS=16|32 forces one: experiments)
 static bool rows16(const GridX& g, int kernel = 0) {   // kernel: 1 = A, 2 = B (experiments: WL_PAIR_ROWS_A / WL_PAIR_ROWS_B force one kernel's tile height)
   static const int force_all = getenv("WL_PAIR_ROWS") ? atoi(getenv("WL_PAIR_ROWS")) : 0;

@@ -34,6 +34,7 @@ struct wl_mg {
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
   bool use_xdefer = true;   // pair smoother: the V-cycle's `x += ω·x_c↓` is applied by kernel B together with its own increment (wl::XDefer)
+  bool overlap_smooth = true;   // z-slabs: the one deep r exchange of a smooth! overlaps kernel A's interior planes (boundary slices after the wait)
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
   bool tail_ok(int first) const;
   int tail(int first, float w, hipStream_t s);

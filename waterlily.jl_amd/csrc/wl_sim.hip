@@ -640,6 +640,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "tail") { s->mg->use_tail = value != 0; return 0; }
   if (n == "tail_lds") { wl::tail_lds_enable(value); return 0; }
   if (n == "xdefer") { s->mg->use_xdefer = value != 0; return 0; }
+  if (n == "overlap_smooth") { s->mg->overlap_smooth = value != 0; return 0; }
   if (n == "body_tile") { wl::conv_body_tile_enable(value); return 0; }
   if (n == "skip_fill") { s->mg->skip_fill = value != 0; return 0; }
   if (n == "defer_shift") { s->mg->defer_shift = value != 0; return 0; }
