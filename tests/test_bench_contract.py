@@ -91,3 +91,19 @@ def test_two_rank_rehearsal_on_one_gpu_prints_n_gpus_2():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert line["n_gpus"] == 2 and line["config"]["transport"] == "CallbackComm" and line["value"] > 0
     assert line["config"]["parallelism"] == "zslab2" and line["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_carries_roofline_probe_and_cpu_baseline():
+    """the default single-GPU line at a small size: the contract keys, the roofline on the kernels' own bytes, the live bandwidth probe and the CPU
+    baseline (port) with its serial companion"""
+    r, line = run_bench("--size", "128", "--steps", "5", "--warmup", "2", "--cpu-budget", "3", timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["dtype"] == "f32" and line["vs_baseline"] is None and line["value"] > 0
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["probe"]["achieved"] > 500.0 and 0 < roof["probe"]["frac_of_peak"] < 1        # a trivial 5-stream kernel on this device, GB/s
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["serial"]["cores"] == 1
