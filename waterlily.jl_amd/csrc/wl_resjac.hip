@@ -17,16 +17,6 @@
 #include "wl_common.hpp"
 
 namespace {
-#define RJ_X 32
-#define RJ_Y 32
-#define RJ_N (RJ_X * RJ_Y)
-#define RJ_W (RJ_X + 2)
-#define RJ_H ((RJ_Y + 2) * RJ_W)
-#define RJ_SZ (2 * RJ_H)
-#define RJ_HX 2
-#define RJ_HY 2
-#define RJ_CX (2 * RJ_X - 2 * RJ_HX)   // 60 core cells
-#define RJ_CY (RJ_Y - 2 * RJ_HY)       // 28 core rows
 
 __device__ __forceinline__ float rj_cf(int Ia, int Na, float c) { return (Ia <= 2 || Ia >= Na) ? 0.f : c; }
 __device__ __forceinline__ float rj_inv(float d) { return (d == 0.f) ? d : 1.0f / d; }
@@ -38,144 +28,20 @@ __device__ __forceinline__ void rj_st2(float* __restrict__ p, unsigned o, float2
 int g_resjac_on = 1;
 long g_resjac_min = 8L << 20;   // cells: below this the extra host read of Σr costs more than the fusion saves
 
-__global__ void __launch_bounds__(RJ_N, 8) k_resjac(GridX g, float* __restrict__ xout, float* __restrict__ rout, const float* __restrict__ p, const float* __restrict__ u,
-                                                    float dt, float w, wl::ConstL cl, int zchunk, double* __restrict__ psum, double* __restrict__ pl1, float* __restrict__ pmax) {
-  __shared__ float sX[2][RJ_SZ];   // x' = x·dt of the plane whose residual is evaluated (even-x array, then odd-x array)
-  __shared__ float sE[2][RJ_SZ];   // ϵ = r·iD of the plane that is relaxed
-  const int ntx = (g.nx - 1 + RJ_CX - 1) / RJ_CX, nty = (g.ny - 2 + RJ_CY - 1) / RJ_CY;
-  const int ntiles = ntx * nty;
-  const unsigned h = blockIdx.x, q = h & 7u, sblk = h >> 3;
-  const unsigned per = (unsigned)((ntiles + 7) >> 3);      // XCD q walks a contiguous range of tiles
-  const int c = (int)(sblk / per);
-  const int tl = (int)(q * per + (sblk - (unsigned)c * per));
-  double nsum = 0.0, nl1 = 0.0; float nmax = 0.f;
-  const int ks = g.k0 + c * zchunk, ke = (ks + zchunk < g.k1) ? ks + zchunk : g.k1;
-  if (tl < ntiles && ks < ke) {
-    const int tx = tl % ntx, ty = tl / ntx;
-    const int lx = threadIdx.x % RJ_X, ly = threadIdx.x / RJ_X;
-    const int i0 = tx * RJ_CX - RJ_HX + 2 * lx, j = 1 + ty * RJ_CY - RJ_HY + ly;       // cells (i0, i0+1) of row j, 0-based with ghosts; i0 even
-    const int lq = (ly + 1) * RJ_W + lx + 1;
-    const bool indom = i0 >= 0 && i0 <= g.nx - 2 && j >= 0 && j < g.ny;
-    const bool jin = j >= 1 && j <= g.ny - 2;
-    const bool in0 = indom && jin && i0 >= 2, in1 = indom && jin && i0 + 1 <= g.nx - 2;  // interior cells
-    const bool corep = 2 * lx >= RJ_HX && 2 * lx < 2 * RJ_X - RJ_HX && ly >= RJ_HY && ly < RJ_Y - RJ_HY;
-    const bool st0 = corep && in0, st1 = corep && in1;
-    const unsigned oc = indom ? (unsigned)i0 + (unsigned)j * (unsigned)g.sy : 0u;
-    const unsigned sz = (unsigned)g.sz, cs = (unsigned)g.cs;
-    for (int qq = threadIdx.x; qq < RJ_SZ; qq += RJ_N) { sX[0][qq] = 0.f; sX[1][qq] = 0.f; sE[0][qq] = 0.f; sE[1][qq] = 0.f; }
-    // in-plane face coefficients of the pair (wall faces: 0) and the partial diagonals  — set_diag!'s order, src/Poisson.jl:49-55
-    const float cxa = rj_cf(i0 + 1, g.nx, cl.c[0]), cxb = rj_cf(i0 + 2, g.nx, cl.c[0]), cxc = rj_cf(i0 + 3, g.nx, cl.c[0]);
-    const float ky = rj_cf(j + 1, g.ny, cl.c[1]), kyp = rj_cf(j + 2, g.ny, cl.c[1]);
-    float dxy0 = 0.f; dxy0 -= (cxa + cxb); dxy0 -= (ky + kyp);
-    float dxy1 = 0.f; dxy1 -= (cxb + cxc); dxy1 -= (ky + kyp);
-    const float c2 = cl.c[2];
-    const int oth0 = RJ_H + lq - 1, oth1 = lq + 1;     // x-neighbour outside the pair: odd cell of the left thread / even cell of the right thread
-    auto plane_ok = [&](int K) { return K >= 0 && K <= g.nz - 1; };
-    auto ldp = [&](int K) -> float2 {                  // x' = x·dt of plane K (all cells of the array; 0 outside it)
-      if (!(indom && plane_ok(K))) return make_float2(0.f, 0.f);
-      const float2 v = rj_ld2(p, oc + (unsigned)K * sz);
-      return make_float2(v.x * dt, v.y * dt);
-    };
-    auto lduz = [&](int K) -> float2 { return (indom && plane_ok(K) && (in0 || in1)) ? rj_ld2(u, 2u * cs + oc + (unsigned)K * sz) : make_float2(0.f, 0.f); };
-    const int K0 = ks - 1;
-    float2 xm = ldp(K0 - 1), x0 = ldp(K0), xp;
-    float2 uz0 = lduz(K0), uzp;
-    float2 em1 = {0.f, 0.f}, e0 = em1, e1 = em1;       // ϵ of planes K−2, K−1, K
-    float2 r1 = em1, r0 = em1;                         // r of planes K−1, K
-    __syncthreads();                                                // (the zero fill above is by other threads)
-    sX[K0 & 1][lq] = x0.x; sX[K0 & 1][lq + RJ_H] = x0.y;
-    for (int K = K0; K <= ke; K++) {
-      // ---- loads of this step: x', u_z of plane K+1 (the z-neighbours), u_x, u_y of plane K
-      xp = ldp(K + 1); uzp = lduz(K + 1);
-      const bool planeK = K >= g.k0 && K < g.k1;
-      float2 ux = {0.f, 0.f}, uy = ux, uyp = ux; float uxr = 0.f;
-      if (planeK && (in0 || in1)) {
-        const unsigned o = oc + (unsigned)K * sz;
-        ux = rj_ld2(u, o); uxr = u[o + 2];
-        uy = rj_ld2(u, cs + o); uyp = rj_ld2(u, cs + o + (unsigned)g.sy);
-      }
-      __syncthreads();                                              // x'(K) and ϵ(K−1) of the previous step are complete; its readers are done
-      sX[(K + 1) & 1][lq] = xp.x; sX[(K + 1) & 1][lq + RJ_H] = xp.y;
-      // ---- residual! on plane K          r = iD==0 ? 0 : z − A·x'   (k_div_residual's statements)
-      const float lz = rj_cf(g.gk + K + 1, g.gnz, c2), lzp = rj_cf(g.gk + K + 2, g.gnz, c2);    // z-faces below / above plane K
-      const float zs = lz + lzp;
-      const float d0 = dxy0 - zs, d1 = dxy1 - zs;                   // D of the two cells
-      const float id0 = rj_inv(d0), id1 = rj_inv(d1);
-      r1 = r0; em1 = e0; e0 = e1;
-      r0 = make_float2(0.f, 0.f); e1 = r0;
-      if (planeK) {
-        const float* __restrict__ SX = sX[K & 1];
-        if (in0) {
-          float dv = 0.f;
-          dv += ux.y - ux.x;
-          dv += uyp.x - uy.x;
-          dv += uzp.x - uz0.x;
-          float s = x0.x * d0;
-          s += (SX[oth0] * cxa + x0.y * cxb);
-          s += (SX[lq - RJ_W] * ky + SX[lq + RJ_W] * kyp);
-          s += (xm.x * lz + xp.x * lzp);
-          r0.x = (d0 == 0.f) ? 0.f : dv - s;
-          e1.x = r0.x * id0;
-        }
-        if (in1) {
-          float dv = 0.f;
-          dv += uxr - ux.y;
-          dv += uyp.y - uy.y;
-          dv += uzp.y - uz0.y;
-          float s = x0.y * d1;
-          s += (x0.x * cxb + SX[oth1] * cxc);
-          s += (SX[RJ_H + lq - RJ_W] * ky + SX[RJ_H + lq + RJ_W] * kyp);
-          s += (xm.y * lz + xp.y * lzp);
-          r0.y = (d1 == 0.f) ? 0.f : dv - s;
-          e1.y = r0.y * id1;
-        }
-        if (K >= ks && K < ke) {                                    // the planes this workgroup owns: Σr, L₁, L∞ of its core cells
-          const float a0 = st0 ? r0.x : 0.f, a1 = st1 ? r0.y : 0.f;
-          nsum += (double)a0; nsum += (double)a1;
-          nl1 += (double)fabsf(a0); nl1 += (double)fabsf(a1); nmax = fmaxf(nmax, fmaxf(fabsf(a0), fabsf(a1)));
-        }
-      }
-      sE[K & 1][lq] = e1.x; sE[K & 1][lq + RJ_H] = e1.y;
-      // ---- Jacobi! on plane P = K−1          ϵ = r·iD ; r −= ω·Aϵ ; x += ω·ϵ   (k_jacobi_march_cl's statements, no pending shift)
-      const int P = K - 1;
-      if (P >= ks && P < ke && (st0 || st1)) {
-        const float* __restrict__ SE = sE[P & 1];
-        const float lzP = rj_cf(g.gk + P + 1, g.gnz, c2), lzpP = lz;          // z-faces below / above plane P (the upper one is plane K's lower)
-        const float zsP = lzP + lzpP;
-        float2 rn, xn;
-        {
-          float s = e0.x * (dxy0 - zsP);
-          s += (SE[oth0] * cxa + e0.y * cxb);
-          s += (SE[lq - RJ_W] * ky + SE[lq + RJ_W] * kyp);
-          s += (em1.x * lzP + e1.x * lzpP);
-          rn.x = r1.x - w * s; xn.x = xm.x + w * e0.x;
-        }
-        {
-          float s = e0.y * (dxy1 - zsP);
-          s += (e0.x * cxb + SE[oth1] * cxc);
-          s += (SE[RJ_H + lq - RJ_W] * ky + SE[RJ_H + lq + RJ_W] * kyp);
-          s += (em1.y * lzP + e1.y * lzpP);
-          rn.y = r1.y - w * s; xn.y = xm.y + w * e0.y;
-        }
-        const unsigned oP = oc + (unsigned)P * sz;
-        rj_st2(rout, oP, rn, st0, st1);
-        rj_st2(xout, oP, xn, st0, st1);
-      }
-      xm = x0; x0 = xp; uz0 = uzp;
-    }
-  }
-  // one partial (Σr, Σ|r|, max|r|) per workgroup
-  __shared__ double shs[RJ_N / 64], shl[RJ_N / 64]; __shared__ float shm[RJ_N / 64];
-  nsum = wave_sum(nsum); nl1 = wave_sum(nl1); nmax = wave_max(nmax);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) { shs[threadIdx.x >> 6] = nsum; shl[threadIdx.x >> 6] = nl1; shm[threadIdx.x >> 6] = nmax; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double a = 0.0, l = 0.0; float mx = 0.f;
-    for (int qq = 0; qq < RJ_N / 64; qq++) { a += shs[qq]; l += shl[qq]; mx = fmaxf(mx, shm[qq]); }
-    psum[blockIdx.x] = a; pl1[blockIdx.x] = l; pmax[blockIdx.x] = mx;
-  }
-}
+// The kernel exists for two tile heights (as the pair smoother): 64×32 cells (1024 threads, 82 % of a tile is core) where the launch fills the chip for
+// many rounds, 64×16 cells (512 threads, 70 % core, four workgroups per CU) where it cannot — there the kernel is bound by the latency of a plane-step
+// (its loads are consumed in the step that issues them; the other resident workgroups are what hides them).
+#define RJ_Y 32
+#define RJ_NS rj32
+#include "wl_resjac_body.inc"
+#undef RJ_Y
+#undef RJ_NS
+#define RJ_Y 16
+#define RJ_NS rj16
+#include "wl_resjac_body.inc"
+#undef RJ_Y
+#undef RJ_NS
+
 // x_out = x·dt on the cells the march does not own: the ghost shell (mom_project!'s `b.x .*= dt` scales ALL cells, src/Flow.jl:225)
 __global__ void k_scale_shell(GridX g, float* __restrict__ xout, const float* __restrict__ p, float dt) {
   const int k = blockIdx.y;
@@ -250,12 +116,17 @@ int shell_nonzero(const float* a, const GridX& g, int* dev_flag, hipStream_t s) 
 }
 int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s, bool shell) {
   if (xout == x) { wl_set_error("resjac: output aliases input"); return WL_EINVAL; }
-  const int ntiles = ((g.nx - 1 + RJ_CX - 1) / RJ_CX) * ((g.ny - 2 + RJ_CY - 1) / RJ_CY), per = (ntiles + 7) >> 3;
   const int np = g.k1 - g.k0;
+  // 16-row tiles (512 threads, four resident workgroups per CU): measured faster at every size (tools/rj_rows.sh: head 0.30 -> 0.275 ms/step at 256³,
+  // 1.63 -> 1.55 at 512³ — the latency hiding of four workgroups outweighs the 12 % more halo traffic); WL_RJ_ROWS=32 brings the 1024-thread tiles back
+  static const int rows_env = getenv("WL_RJ_ROWS") ? atoi(getenv("WL_RJ_ROWS")) : 0;
+  const bool r16 = rows_env != 32;
+  const int ntiles = r16 ? rj16::rj_tiles(g) : rj32::rj_tiles(g), per = (ntiles + 7) >> 3;
+  const long SX = r16 ? rj16::rj_slots_per_xcd() : rj32::rj_slots_per_xcd();
   static const int envc = getenv("WL_RJ_CHUNK") ? atoi(getenv("WL_RJ_CHUNK")) : 0;
   int zc = envc;
   if (zc <= 0) {
-    // equal workgroups run in rounds of 32 CUs × 2 resident workgroups per XCD (tile ranges are dealt XCD by XCD): minimise
+    // equal workgroups run in rounds of 32 CUs × the resident workgroups per CU on every XCD (tile ranges are dealt XCD by XCD): minimise
     // rounds × (planes per chunk + the 2 warm-up planes), with a balance penalty for few rounds — as wl_fused2's zchunk2.  The former fixed target of
     // 3072 workgroups gave 6.2 rounds at 512³, i.e. a seventh, almost empty one.
     static const int chforce = getenv("WL_RJ_CHUNKS") ? atoi(getenv("WL_RJ_CHUNKS")) : 0;     // experiments: number of chunks
@@ -263,9 +134,9 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
     for (int chunks = 1; chunks <= np; chunks++) {
       const int z = (np + chunks - 1) / chunks;
       if (z < 8) break;
-      const long W = (long)per * ((np + z - 1) / z), rounds = (W + 63) / 64;
+      const long W = (long)per * ((np + z - 1) / z), rounds = (W + SX - 1) / SX;
       double cost = (double)rounds * (z + 2) * (1.0 + 0.3 / (double)rounds);
-      if (W < 64) cost = (z + 2) * 1.3;
+      if (W < SX) cost = (z + 2) * 1.3;
       if (chforce > 0) cost = (chunks == chforce) ? 0.0 : 1e30;
       if (best < 0 || cost < best) { best = cost; zc = z; }
     }
@@ -275,7 +146,8 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
   const unsigned nb = (unsigned)(8 * per * nch);
   if (nb > WL_MAXPART) { wl_set_error("resjac: too many workgroups for the reduction workspace"); return WL_EINVAL; }
   if (shell) hipLaunchKernelGGL(k_scale_shell, dim3(8, (unsigned)g.nz), dim3(WL_BLOCK), 0, s, g, xout, x, dt);
-  hipLaunchKernelGGL(k_resjac, dim3(nb), dim3(RJ_N), 0, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm);
+  if (r16) rj16::rj_launch(nb, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm);
+  else rj32::rj_launch(nb, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm);
   hipLaunchKernelGGL(k_resjac_fin, dim3(1), dim3(WL_BLOCK), 0, s, (const double*)ws.pa, (const double*)ws.pb, (const float*)ws.pm, (int)nb, ws.res_d, ws.res_f, slot_d, slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
