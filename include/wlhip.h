@@ -194,7 +194,7 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    "bcfold"[1] BC!(u,U) for a tuple U folded into the stores of the kernels that produce u (single domain, no exit, no periodic direction):
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
-   mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[8 Mi cells] size gate (tests: 0)
+   mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[6 Mi cells] size gate (tests: 0)
    "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0)
    "xdefer"[1] pair smoother: the V-cycle's x += ω·x_c↓ is applied by kernel B together with its own increment (x makes one round trip per smooth!)
    "tail_lds"[1] the single-launch coarse tail keeps r, x, ϵ of its levels in LDS (0: in global memory)

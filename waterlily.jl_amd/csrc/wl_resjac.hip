@@ -26,7 +26,7 @@ __device__ __forceinline__ void rj_st2(float* __restrict__ p, unsigned o, float2
   else { if (s0) p[o] = v.x; if (s1) p[o + 1] = v.y; }
 }
 int g_resjac_on = 1;
-long g_resjac_min = 8L << 20;   // cells: below this the extra host read of Σr costs more than the fusion saves
+long g_resjac_min = 6L << 20;   // cells: below this the extra host read of Σr costs more than the fusion saves (tools/rj_gate.sh: 192³ −3.5 %, 160³ even, 128³ +4 %)
 
 // The kernel exists for two tile heights (as the pair smoother): 64×32 cells (1024 threads, 82 % of a tile is core) where the launch fills the chip for
 // many rounds, 64×16 cells (512 threads, 70 % core, four workgroups per CU) where it cannot — there the kernel is bound by the latency of a plane-step
