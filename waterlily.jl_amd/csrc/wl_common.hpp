@@ -92,6 +92,19 @@ __device__ __forceinline__ bool wl_tile(const GridX& g, long& m, int& p) {
   m = bx * WL_BLOCK + threadIdx.x;
   return bx < nbx;
 }
+// The same grid read in LINEAR order: block h takes chunk h mod nb8 of plane slot h / nb8 (nb8 = the plane's 256-cell chunks rounded up to
+// a multiple of 8, so that a chunk position belongs to the same XCD on every plane: its z-neighbours are hits in that XCD's L2).  With one
+// plane per slot the chip sweeps the arrays front to back like an element-wise kernel — the order in which HBM delivers the most
+// (profiles/r03_shape_probe.md: 5.5 TB/s against 4.6 for z-marching chunks of the projection tail's 4 reads + 4 writes).
+__device__ __forceinline__ bool wl_tile_lin(const GridX& g, long& m, int& p) {
+  const long nbx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
+  const unsigned nb8 = (unsigned)(((nbx + 7) >> 3) << 3);
+  const unsigned h = blockIdx.x;
+  p = (int)(h / nb8);
+  const long bx = (long)(h - (unsigned)p * nb8);
+  m = bx * WL_BLOCK + threadIdx.x;
+  return bx < nbx;
+}
 __device__ __forceinline__ int wl_nslots(const GridX& g) {   // number of plane slots of this launch
   const long nbx = (g.sz + WL_BLOCK - 1) / WL_BLOCK;
   return (int)(gridDim.x / (8u * (unsigned)((nbx + 7) >> 3)));

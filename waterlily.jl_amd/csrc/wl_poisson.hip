@@ -135,12 +135,16 @@ __global__ void k_div_residual(GridX g, float* __restrict__ z, float* __restrict
   acc = block_sum(acc);
   if (threadIdx.x == 0) part[blockIdx.x] = acc;
 }
+// float -> int that orders like the float (−0 < +0 aside): maxima of many blocks through integer atomicMax into a few slots
+#define WL_ENC_SLOTS 1024
+__device__ __forceinline__ int wl_enc_f(float v) { const int b = __float_as_int(v); return b >= 0 ? b : (b ^ 0x7FFFFFFF); }
+__device__ __forceinline__ float wl_dec_f(int k) { return __int_as_float(k >= 0 ? k : (k ^ 0x7FFFFFFF)); }
 // mom_project! tail (src/Flow.jl:227-230): u[I,i] -= L[I,i]·∂ᵢx ; p_out = x/dt (ALL cells), p_out ≠ x
 template <int D, int CL>
 __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl, int zchunk,
-                                  int p0, int p1, BcFold bc) {   // local planes [p0,p1) of this launch; bc.on: BC!(u,U) folded into the stores (wl_bcfold.hpp)
+                                  int p0, int p1, BcFold bc, int lin) {   // local planes [p0,p1) of this launch; bc.on: BC!(u,U) folded into the stores (wl_bcfold.hpp); lin: linear block order (wl_tile_lin)
   int i, j; long m; int pz;
-  wl_tile(g, m, pz);
+  if (lin) wl_tile_lin(g, m, pz); else wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
   const bool inij = interior_ij(g, i, j);
   const int ks = p0 + pz * zchunk, ke = (ks + zchunk < p1) ? ks + zchunk : p1;
@@ -175,9 +179,9 @@ __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* _
 // (non-periodic, no exitBC).  Cells outside the interior of u_out are left for BC! to write.
 template <int D, int CL>
 __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout,
-                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1, int store_sigma, BcFold bc) {
+                              float* __restrict__ sigma, float dt, wl::ConstL cl, int zchunk, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1, int store_sigma, BcFold bc, int lin) {
   int i, j; long m; int pz;
-  wl_tile(g, m, pz);
+  if (lin) wl_tile_lin(g, m, pz); else wl_tile(g, m, pz);      // lin: linear block order, one plane per block; the maxima go to WL_ENC_SLOTS order-encoded integers
   float mx = -INFINITY;
   if (cell_ij(g, m, i, j)) {
     const bool inij = interior_ij(g, i, j);
@@ -222,7 +226,17 @@ __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __
     }
   }
   mx = block_max(mx);
-  if (threadIdx.x == 0) pmax[blockIdx.x] = mx;
+#ifdef WL_CFL_NOATOM   // timing experiment (wrong Δt): what the atomics cost
+  if (threadIdx.x == 0) { if (lin) reinterpret_cast<int*>(pmax)[blockIdx.x & (WL_ENC_SLOTS - 1)] = wl_enc_f(mx); else pmax[blockIdx.x] = mx; }
+#else
+  if (threadIdx.x == 0) { if (lin) atomicMax(reinterpret_cast<int*>(pmax) + (blockIdx.x & (WL_ENC_SLOTS - 1)), wl_enc_f(mx)); else pmax[blockIdx.x] = mx; }
+#endif
+}
+__global__ void k_enc_init(int* __restrict__ p) { p[threadIdx.x] = (int)0x80000000; }
+__global__ void k_fin_max_enc(const int* __restrict__ p, float* __restrict__ om) {
+  float mx = -INFINITY;
+  for (int q = threadIdx.x; q < WL_ENC_SLOTS; q += WL_BLOCK) { const int k = p[q]; if (k != (int)0x80000000) mx = fmaxf(mx, wl_dec_f(k)); }
+  mx = block_max(mx); if (threadIdx.x == 0) *om = mx;
 }
 __global__ void k_fin_max2(const float* __restrict__ pmax, int n, float* __restrict__ om) {
   float mx = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
@@ -1004,11 +1018,15 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, off, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
+// linear block order (wl_tile_lin), one plane per block: bit 0 = the first projection tail (1.04 -> 0.875 ms at 512³), bit 1 = the second (project_cfl: SLOWER, 1.33 -> 1.55 ms — its
+// 13 loads per cell make it L1/L2-bound, not HBM-bound; the integer atomics are not the cause, profiles/r03_experiments.md).  Default 1.
+static int tail_lin(int bit) { static const int v = getenv("WL_TAIL_LIN") ? atoi(getenv("WL_TAIL_LIN")) : 1; return (v >> bit) & 1; }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold) {
-  const int zc = wl_march_chunk(g, g.nz);
+  const int lin = tail_lin(0) && g.D == 3;
+  const int zc = lin ? 1 : wl_march_chunk(g, g.nz);
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
-  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, 0, g.nz, bc);
+  DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, 0, g.nz, bc, lin);
   WL_LAUNCH_CHECK(); return 0;
 }
 // level with a body: planes [0,na) and [nb,nz) with the constant-coefficient pattern `far`, [na,nb) reading L (see div_residual_split)
@@ -1019,7 +1037,7 @@ int project_unscale_split(float* u, const float* L, const float* x, float* pout,
     if (np <= 0) continue;
     const ConstL& cl = q == 1 ? near : far;
     const int zc = wl_march_chunk(g, np);
-    DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(np, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, lo[q], hi[q], BcFold{0, {0.f, 0.f, 0.f}});
+    DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(np, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, lo[q], hi[q], BcFold{0, {0.f, 0.f, 0.f}}, 0);
   }
   WL_LAUNCH_CHECK(); return 0;
 }
@@ -1030,10 +1048,13 @@ int project_cfl(float* uout, const float* uin, const float* L, const float* x, f
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
-  const int zc = wl_march_chunk(g, g.nz);
+  const int lin = tail_lin(1) && g.D == 3;
+  const int zc = lin ? 1 : wl_march_chunk(g, g.nz);
   const dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
-  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz, store_sigma, bc);
-  hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
+  if (lin) hipLaunchKernelGGL(k_enc_init, dim3(1), dim3(WL_ENC_SLOTS), 0, s, reinterpret_cast<int*>(ws.pm));
+  DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm, 0, g.nz, store_sigma, bc, lin);
+  if (lin) hipLaunchKernelGGL(k_fin_max_enc, dim3(1), dim3(WL_BLOCK), 0, s, reinterpret_cast<const int*>(ws.pm), ws.res_f + slot_f);
+  else hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, (int)grid.x, ws.res_f + slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }
 int project_cfl_split(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& near, const ConstL& far,
@@ -1050,7 +1071,7 @@ int project_cfl_split(float* uout, const float* uin, const float* L, const float
     const int zc = wl_march_chunk(g, np);
     const dim3 grid = wl_plane_grid(g, wl_march_slots(np, zc));
     if (off + (int)grid.x > WL_MAXPART) { wl_set_error("project_cfl_split: too many partial maxima"); return WL_EINVAL; }
-    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q], store_sigma, BcFold{0, {0.f, 0.f, 0.f}});
+    DSEL2(g.D, cl.on, k_project_cfl, grid, dim3(WL_BLOCK), 0, s, g, uout, uin, L, x, pout, sigma, dt, cl, zc, kfirst, klast, ws.pm + off, lo[q], hi[q], store_sigma, BcFold{0, {0.f, 0.f, 0.f}}, 0);
     off += (int)grid.x;
   }
   hipLaunchKernelGGL(k_fin_max2, dim3(1), dim3(WL_BLOCK), 0, s, ws.pm, off, ws.res_f + slot_f);
