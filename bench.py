@@ -275,36 +275,33 @@ def main():
     n_warm = len(sim.pois_n)
     all_phases = args.phases or (any(k.startswith("WL_OPT_") for k in os.environ) and not args.no_phases)
     check(lib.wl_prof_enable(1 if all_phases else 2))
+    import ctypes as C
+    def counter(name):
+        v = C.c_long()
+        check(lib.wl_sim_counter(sim._h, name.encode(), C.byref(v)))
+        return int(v.value)
+    l0, rj0, rd0 = int(lib.wl_launch_count()), counter("resjac"), counter("resjac_redo")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sim.mom_step_()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    launches_per_step = (int(lib.wl_launch_count()) - l0) / args.steps
     prof = read_prof(lib)
     check(lib.wl_prof_enable(0))
     ncell = float(N) ** 3
     pn = sim.pois_n[n_warm:]
     roof = build_roofline(prof, ncell, bool(sim.const_levels()[0]), sim.smoother_kinds()[0], N, use_traffic=True)
-    # the practical ceiling of kernel B's read/write mix on THIS device (a trivial kernel with the same streams and access shape), measured
-    # after the timed region; memory of the simulation is still allocated, so the probe box is at most 512³ (2 GiB)
-    try:
-        import ctypes as C
-        pg = C.c_double()
-        check(lib.wl_probe_mix(min(512, max(64, (N // 64) * 64)), 5, C.byref(pg), None))
-        roof["probe"] = {"what": "wl_probe_mix: 3 fields read + 2 written (20 B/cell) in kernel B's access shape (64x32-cell tiles, z-march), no arithmetic — "
-                                 "the practical ceiling of this mix on this device; `peak` stays the 8 TB/s specification",
-                         "achieved": pg.value, "unit": "GB/s", "frac_of_peak": pg.value / HBM_PEAK_GBS,
-                         "smoother_traffic_vs_probe": (roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9 / pg.value) if roof.get("traffic") else None}
-    except Exception as e:      # the probe is context for the reader, not part of the measurement
-        roof["probe"] = {"error": str(e)}
     out = {
         "metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": ncell * args.steps / el, "unit": "cells*steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false (BASELINE configs[4] domain on 1 GPU)",
                    "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1]),
-                   "constant_coefficient_levels": sim.const_levels(), "smoother_kinds": sim.smoother_kinds()},
+                   "constant_coefficient_levels": sim.const_levels(), "smoother_kinds": sim.smoother_kinds(),
+                   # kernel launches per mom_step! in the timed region; solves whose fused projection head stood / had to be redone (residual!'s mean shift due)
+                   "launches_per_step": launches_per_step, "resjac": counter("resjac") - rj0, "resjac_redo": counter("resjac_redo") - rd0},
         "roofline": roof,
         "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items() if v["launches"]},
     }

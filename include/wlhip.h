@@ -167,7 +167,9 @@ typedef struct wl_sim_desc {
      the handle PERMUTES the roles of the three arrays {u, u0, us} from step to step.  With caller-owned u and u0:
        us given : full-speed path; after every wl_sim_mom_step read the current roles back with wl_sim_field(s,"u"|"u0"|"us")
                   (the Julia binding re-points its HipArray objects; the three buffers stay the caller's to free);
-       us NULL  : pointers never move — `u⁰ .= u` is a copy and conv_diff!/BDIM! run as separate passes (slower). */
+       us NULL  : pointers never move — `u⁰ .= u` is a copy and conv_diff!/BDIM! run as separate passes (slower).
+     Convective exit (exitBC=1, single domain): the buffers rotate as well; BC! leaves the x-exit face of u alone (saveexit, src/core.jl:207),
+     so that face is copied from the old role holder to the new one at each rotation (one strided plane).  On z-slabs exitBC flows keep the copy. */
   float *us;
 } wl_sim_desc;
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc);
@@ -282,21 +284,6 @@ int wl_allgather_planes(wl_comm* c, float* a, const wl_grid* view, int ncomp, vo
 int wl_grid_slab(wl_grid* out, int D, const int32_t* global_dims_with_ghosts, int rank, int size, int halo);
 /* Simulation on a z-slab: desc->dims are the GLOBAL interior sizes; arrays are allocated by the handle (caller pointers must be NULL) */
 int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm);
-
-/* ---- measurement hooks (bench.py): HIP-event pairs recorded on the launch stream around named launches ----
- * slots: 0 fine-level GS colour sweep (one launch), 1 fine-level smooth! (GaussSeidelRB! as a whole),
- *        2 fine-level Jacobi!, 3 conv_diff!, 4 fine-level residual!+norms, 5 BDIM!, 6 fine-level prolongate+increment,
- *        7 coarse levels (everything below level 1 of a V-cycle), 8 mom_step! as a whole,
- *        9 / 10 fine-level kernels A / B of the temporally blocked smoother (wl_fused.hip)                        */
-enum { WL_PROF_GS_SWEEP = 0, WL_PROF_SMOOTH = 1, WL_PROF_JACOBI = 2, WL_PROF_CONVDIFF = 3, WL_PROF_RESIDUAL = 4,
-       WL_PROF_BDIM = 5, WL_PROF_PROLONG = 6, WL_PROF_COARSE = 7, WL_PROF_STEP = 8, WL_PROF_GS_A = 9, WL_PROF_GS_B = 10, WL_PROF_NSLOTS = 11 };
-/* Bandwidth probe for the roofline report (wl_probe.hip): smoother kernel B's memory mix (3 fields read, 2 written, 20 B/cell) in its
- * access shape (64×32-cell tiles, z-march) with trivial arithmetic on an n³ box (n a multiple of 64; allocates and frees 16·n³ bytes).
- * *gbs = 20·n³ B ÷ average launch time over `reps` launches: the practical ceiling of that mix on this device. */
-int wl_probe_mix(int n, int reps, double* gbs, void* stream);
-int wl_prof_enable(int on);                                     /* 0 off, 1 all slots, 2 only slots 9 and 10 (each event pair costs a few µs of
-                                                                    stream time); also resets all slots */
-int wl_prof_read(int slot, int* host_count, double* host_total_ms);   /* synchronises the device */
 
 #ifdef __cplusplus
 }

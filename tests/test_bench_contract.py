@@ -95,7 +95,7 @@ def test_two_rank_rehearsal_on_one_gpu_prints_n_gpus_2():
 
 @pytest.mark.gpu
 def test_single_gpu_line_carries_roofline_probe_and_cpu_baseline():
-    """the default single-GPU line at a small size: the contract keys, the roofline on the kernels' own bytes, the live bandwidth probe and the CPU
+    """the default single-GPU line at a small size: the contract keys, the roofline on the kernels' own bytes, launch and path counters, and the CPU
     baseline (port) with its serial companion"""
     r, line = run_bench("--size", "128", "--steps", "5", "--warmup", "2", "--cpu-budget", "3", timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -104,6 +104,8 @@ def test_single_gpu_line_carries_roofline_probe_and_cpu_baseline():
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["dtype"] == "f32" and line["vs_baseline"] is None and line["value"] > 0
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
-    assert roof["probe"]["achieved"] > 500.0 and 0 < roof["probe"]["frac_of_peak"] < 1        # a trivial 5-stream kernel on this device, GB/s
+    assert "probe" not in roof                                        # (round 3: the self-made comparator is gone from the line; tools/probe holds the scans)
+    cfg = line["config"]
+    assert cfg["launches_per_step"] > 10 and cfg["resjac"] + cfg["resjac_redo"] >= 0 and cfg["mean_pois_n"] >= 1
     cb = line["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["serial"]["cores"] == 1

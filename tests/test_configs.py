@@ -1,6 +1,7 @@
 """BASELINE.json's configurations by name.
 configs[0] (CPU, here): the reference README's 2-D circle (README.md:41-57) — 3·2^5 × 2^6, Re=100, Float64, serial, 10 sim_step! —
   on the oracle: the plumbing case; its 6-level semi-coarsened multigrid hierarchy is SURVEY §8's (98,66)…(5,4).
+configs[0] (GPU): the same workload in Float32 through the 2-D HIP kernels against the oracle in Float32 (VERDICT r02 #6a).
 configs[3] (GPU): sphere (AutoBody sdf) 256³ Re=3700 Float32 — default kernels vs the one-kernel-per-pass general kernels bitwise,
   pressure_force of both paths equal; and the same flow at 64³ against the oracle with the z-split smoother forced on.
 The drag history of configs[3] has no reference-held value (no Julia here, none in the reference's tests): PARITY UNPINNED for
@@ -89,3 +90,44 @@ def test_config3_sphere_64_matches_oracle_with_zsplit(w, oracle):
         assert np.abs(sg.field("p") - so.p).max() < 5e-4
     fo, fg = so.pressure_force(), sg.pressure_force_sphere(c, R)
     assert np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())
+
+
+@pytest.mark.gpu
+def test_config0_circle_2d_on_the_hip_path_matches_oracle(w, oracle):
+    """configs[0]'s workload — circle 3·2^5 × 2^6, Re=100, ten sim_step! with remeasure on (README.md:41-57) — through the 2-D HIP kernels
+    (wl_sim, D = 2) in Float32 against the oracle in Float32: same multigrid hierarchy, same pois.n, |Δu| ≤ 1e-5 (reductions differ in
+    summation order only), Δt to rounding."""
+    n, m = 3 * 2**5, 2**6
+    radius, center = m / 8, m / 2 - 1
+    Re, U = 100, 1
+    nu = U * 2 * radius / Re
+    so = oracle.Simulation((n, m), (U, 0), 2 * radius, U=U, nu=nu, body=("sphere", (center, center), radius), T=np.float32)
+    sg = w.FusedSimulation((n, m), (U, 0), 2 * radius, U=U, nu=nu, has_body=True)
+    sg.measure_sphere_((center, center), radius, 1.0)
+    # MultiLevelPoisson's 6-level hierarchy, semi-coarsened at the end (src/MultiLevelPoisson.jl:20-48,70), read back from the device handle
+    want = [(98, 66), (50, 34), (26, 18), (14, 10), (8, 6), (5, 4)]
+    assert sg.nlevels() == so.nlevels == 6
+    from waterlily_jl_amd._lib import lib, wl_grid
+    import ctypes as C
+    got = []
+    for l in range(6):
+        g = wl_grid()
+        assert lib().wl_mg_level_grid(lib().wl_sim_pois(sg._h), l, C.byref(g)) == 0
+        assert g.D == 2
+        got.append((g.nx, g.ny))
+    assert got == want == [so.level_dims(l) for l in range(6)]
+    # the measured coefficients agree to rounding (device measure! evaluates the same closed form in Float32)
+    assert np.abs(sg.field("mu0") - so.field("mu0")).max() < 2e-6
+    for step in range(10):
+        so.step(remeasure=True)
+        sg.measure_sphere_((center, center), radius, 1.0)       # sim_step!(remeasure=true): measure!(sim) + update!(pois), src/WaterLily.jl:136-149
+        sg.mom_step_()
+        assert sg.pois_n == so.pois_n, (step, sg.pois_n, so.pois_n)
+        du = np.abs(sg.field("u") - so.u).max()
+        assert du <= 1e-5, (step, du)
+        assert np.abs(sg.field("p") - so.p).max() <= 2e-4 * max(1.0, np.abs(so.p).max())
+    assert len(sg.pois_n) == 20 and max(sg.pois_n[2:]) <= 6
+    dg, do = np.array(sg.dt, dtype=np.float64), np.array(so.dt, dtype=np.float64)
+    assert dg.shape == do.shape == (11,) and np.abs(dg / do - 1).max() < 1e-5
+    fo, fg = so.pressure_force(), sg.pressure_force_sphere((center, center), radius)
+    assert fg[0] < 0 and np.allclose(fg, fo, rtol=2e-3, atol=2e-3 * np.abs(fo).max())

@@ -1,6 +1,6 @@
 """Committed golden vectors (tests/golden/golden_r01.npz, made by tests/golden/make_golden.py from the oracle):
  - not gpu: the oracle still reproduces them (guards the checker itself against drift), and the C-ABI library loads
-   and exports every symbol include/wlhip.h declares (no compute call without a GPU);
+   and exports every symbol include/wlhip.h and include/wlhip_bench.h declare (no compute call without a GPU);
  - gpu: the HIP path reproduces them through the C ABI."""
 import os
 import re
@@ -35,7 +35,7 @@ def test_oracle_reproduces_golden(oracle):
 
 def test_library_exports_every_declared_symbol():
     import waterlily_jl_amd as w
-    hdr = open(os.path.join(ROOT, "include", "wlhip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "wlhip.h")).read() + open(os.path.join(ROOT, "include", "wlhip_bench.h")).read()   # the drop-in boundary + the measurement hooks
     declared = set(re.findall(r"\b(wl_[a-z0-9_]+)\s*\(", hdr)) - {"wl_sendrecv_fn", "wl_allgather_fn"}
     lib = w.lib()                                   # binds every entry of SIGNATURES (AttributeError if one is missing)
     missing = [n for n in declared if not hasattr(lib, n)]

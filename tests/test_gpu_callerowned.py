@@ -133,3 +133,42 @@ def test_caller_owned_arrays_with_a_body(w):
             assert np.array_equal(sim.field("u"), r2.field("u")) and np.array_equal(sim.field("p"), r2.field("p")), (with_spare, step)
         assert sim.pois_n() == r2.pois_n
         sim.close()
+
+
+@pytest.mark.parametrize("dims", [(64, 48, 40), (64, 48)])
+def test_convective_exit_rotates_the_buffers_and_matches_oracle(w, oracle, dims):
+    """exitBC=true (src/core.jl:226-233; BC! leaves the exit face alone, :207): the handle-owned flow and a caller-owned flow WITH a spare
+    array rotate their velocity buffers (the exit face travels with the role); a caller-owned flow WITHOUT the spare copies `u⁰ .= u`.
+    All three give the same bits, and they match the oracle to the summation order of the two face means."""
+    rng = np.random.default_rng(11)
+    D = len(dims)
+    Ng = tuple(n + 2 for n in dims)
+    uBC = (1.0,) + (0.0,) * (D - 1)
+    u_init = np.asfortranarray(rng.uniform(-0.2, 0.2, size=Ng + (D,)).astype(np.float32))
+    u_init[..., 0] += 1.0
+    ui = u_init.copy(order="F")
+    oracle.BC(ui, uBC, True, ())                           # Flow(): BC!(u,uBC,exitBC,perdir); exitBC!(u,u,zero(T))   src/Flow.jl:141
+    oracle.exitBC(ui, ui.copy(order="F"), 0.0)
+    so = oracle.Simulation(dims, uBC, dims[0], U=1, nu=0.02, exitBC=True, T=np.float32)
+    so.field("u")[...] = ui; so.field("u0")[...] = ui
+    ref = w.FusedSimulation(dims, uBC, dims[0], U=1, nu=0.02, exitBC=True, u0=u_init)
+    ref.set_field("u", ui); ref.set_field("u0", ui)       # every flow starts from the same bits (the face means of exitBC! are reductions)
+    assert w.lib().wl_sim_field(ref._h, b"us")            # the handle owns a spare array although the exit is convective
+    sims = {sp: CallerOwnedSim(w, dims, uBC, 0.02, u_init, sp, exitBC=True) for sp in (True, False)}
+    for sim in sims.values():
+        sim.arr["u"].copy_(w.to_device(ui)); sim.arr["u0"].copy_(w.to_device(ui))
+    moved = False
+    for step in range(4):
+        so.step(remeasure=False); ref.mom_step_()
+        for sp, sim in sims.items():
+            sim.mom_step()
+            assert np.array_equal(sim.field("u"), ref.field("u")), (sp, step)
+            assert np.array_equal(sim.field("u0"), ref.field("u0")), (sp, step)
+            assert np.array_equal(sim.field("p"), ref.field("p")), (sp, step)
+        moved = moved or sims[True].role["u"] != "u"
+        assert ref.pois_n == so.pois_n
+        assert np.abs(ref.field("u") - so.u).max() < 2e-5, step
+    assert moved and sims[False].role == {"u": "u", "u0": "u0"}
+    for sim in sims.values():
+        assert sim.pois_n() == ref.pois_n
+        sim.close()

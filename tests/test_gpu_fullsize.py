@@ -36,6 +36,26 @@ def test_fast_paths_equal_plain_paths_bitwise_at_256(w):
         assert np.array_equal(sims[tag][1], sims["fast"][1]), tag
 
 
+def test_fast_paths_equal_plain_paths_bitwise_at_128_config1(w):
+    """BASELINE configs[1]: 3-D TGV 128³ Float32, NoBody.  Four mom_step! through the default kernels and through the one-kernel-per-pass
+    general kernels: u, p, pois.n, Δt identical; finite; the solver stays within a few V-cycles."""
+    n = 128
+    res = {}
+    for tag, opts in (("fast", {}), ("plain", {"fused_smoother": 0, "fuse_p": 0, "constl": 0, "fuse_cfl": 0, "store_f": 1, "tail": 0})):
+        s = w.FusedSimulation((n, n, n), (0, 0, 0), n, U=1, nu=n / 1600.0, ic="tgv")
+        for k, v in opts.items():
+            s.set_option(k, v)
+        for _ in range(4):
+            s.mom_step_()
+        res[tag] = (s.field("u"), s.field("p"), s.pois_n, s.dt)
+        del s
+    f, p = res["fast"], res["plain"]
+    assert f[2] == p[2] and f[3] == p[3]
+    assert len(f[2]) == 8 and max(f[2]) <= 4, f[2]
+    assert np.isfinite(f[0]).all() and np.isfinite(f[1]).all() and all(np.isfinite(d) and d > 0 for d in f[3])
+    assert np.array_equal(f[0], p[0]) and np.array_equal(f[1], p[1])
+
+
 @pytest.mark.parametrize("dims", [(96, 80, 72), (144, 96, 48), (200, 136, 104), (320, 64, 40)])
 def test_fast_paths_equal_plain_paths_bitwise_on_odd_shapes(w, dims):
     """non-power-of-two boxes (semi-coarsened hierarchies, tiles and z-chunks that end off the grid): three mom_step! through the

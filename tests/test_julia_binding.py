@@ -5,7 +5,10 @@ What can be checked without Julia is checked:
     listed (or whose line moved) — skipped where the reference is absent (GPU box);
  2. every listed site names the method of the binding that intercepts it, and that method's signature is present in the file;
  3. every `ccall` of the binding names a symbol include/wlhip.h declares, with the declared number of arguments;
- 4. the Julia mirrors of the C structs (WlGrid, WlBody, WlSimDesc) have the fields of include/wlhip.h in order.
+ 4. the Julia mirrors of the C structs (WlGrid, WlBody, WlSimDesc) have the fields of include/wlhip.h in order;
+ 5. dispatch hazards that only a Julia run would show are desk-checked as text rules (round-2 advisor findings): no method signature
+    that is ambiguous with Base's broadcast-style rules, no dictionary keyed by a device array (hashing = scalar getindex per element),
+    no per-step path through scalar getindex, the spare velocity array handed over for every flow, uniform closures kept on the composite.
 The call SEQUENCE the binding performs for the composite time step is executed, through ctypes, by tests/test_gpu_callerowned.py."""
 import json
 import os
@@ -122,3 +125,32 @@ def test_struct_mirrors_match_the_header():
     assert cf == fields
     b = re.search(r"struct WlBody; (.*?) end", src).group(1)
     assert [f.split("::")[0].strip() for f in b.split(";") if f.strip()] == ["kind", "c", "R", "m", "V"]
+
+
+def test_dispatch_hazards_desk_check():
+    src = open(JL, encoding="utf-8").read()
+    code = "\n".join(l.split("#")[0] for l in src.split("\n"))          # comments stripped
+    # (a) BroadcastStyle: Base owns  BroadcastStyle(a::AbstractArrayStyle{Any}, ::DefaultArrayStyle) = a ; a binding method whose second slot is
+    #     ::AbstractArrayStyle (or untyped) would be ambiguous with it for every `hiparray .op scalar`.  Allowed: the one-argument Type form and
+    #     methods whose second slot is exactly ::DefaultArrayStyle (strictly more specific than Base's).
+    meths = re.findall(r"BroadcastStyle\(([^)]*)\)\s*=", code)
+    assert meths, "the binding defines its broadcast style"
+    for sig in meths:
+        args = [a.strip() for a in sig.split(",")]
+        if len(args) == 1:
+            assert args[0].startswith("::Type{<:HipArray}"), sig
+        else:
+            assert len(args) == 2 and args[0] == "::HipStyle" and args[1] == "::Base.Broadcast.DefaultArrayStyle", f"ambiguous with Base: BroadcastStyle({sig})"
+    # (b) no dictionary keyed by device arrays: AbstractArray keys hash through scalar getindex (one wl_d2h per element)
+    assert not re.search(r"(WeakKeyDict|IdDict|Dict)\s*\{\s*(Any|HipArray|HA)", code)
+    assert re.search(r"has_body\(a::HFlow\) = a\.μ₁\.bodied", code) and code.count("a.μ₁.bodied = true") == 2
+    # (c) the composite step does not index device arrays element-wise
+    step = re.search(r"function mom_step!\(a::HFlow\{D\}, b::HipMultiLevel.*?\nend\n", code, re.S).group(0)
+    comp = re.search(r"function composite!\(a::HFlow\{D\}, b::HipMultiLevel.*?\nend\n", code, re.S).group(0)
+    for body in (step, comp):
+        assert not re.search(r"\ba\.(u|u⁰|p|σ|f|V|μ₀|μ₁)\[", body)
+    # (d) every flow hands its spare velocity array to the library (exitBC flows included): `u⁰ .= u` stays a pointer rotation
+    assert "a.μ₁.ptr, spare.ptr))" in comp and "Ptr{Cfloat}(C_NULL) : spare.ptr" not in comp
+    assert 'b.spare.ptr = simfield(sim, "us")' in step and "!a.exitBC" not in step
+    # (e) closures that are uniform in x keep the composite path: tabulated per step through wl_sim_set_forcing
+    assert "(:wl_sim_set_forcing, libwlhip)" in code and "uniform_in_x(a.uBC" in step and "set_forcing!(sim, a)" in step

@@ -145,7 +145,8 @@ SIGNATURES = {
     "wl_allgather_planes": (i32, [P, P, G, i32, P]),
     "wl_grid_slab": (i32, [G, i32, C.POINTER(C.c_int32), i32, i32, i32]),
     "wl_sim_create_slab": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc), P]),
-    "wl_probe_mix": (i32, [i32, i32, C.POINTER(C.c_double), P]),
+    "wl_launch_count": (C.c_long, []),
+    "wl_sim_counter": (i32, [P, C.c_char_p, C.POINTER(C.c_long)]),
     "wl_prof_enable": (i32, [i32]),
     "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),
     "wl_sim_pressure_force_sphere": (i32, [P, C.POINTER(f32), f32, C.POINTER(f64), P]),

@@ -28,6 +28,7 @@ int wl_ctx_ensure() {
   return 0;
 }
 
+long g_wl_launches = 0;
 WlProf& wl_prof() { static WlProf p; return p; }
 ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active(false), idx(0) {
   WlProf& p = wl_prof();

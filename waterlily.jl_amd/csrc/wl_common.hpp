@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/wlhip.h"
+#include "../../include/wlhip_bench.h"
 
 #define WL_WAVE 64
 #define WL_BLOCK 256
@@ -35,7 +36,20 @@ void wl_set_error(const std::string& s);
 #define WL_LAUNCH_CHECK() WL_HIP(hipGetLastError())
 
 static inline hipStream_t wl_stream(void* s) { return (hipStream_t)s; }
+// every kernel launch of the library is counted (wl_launch_count(): bench.py's config.launches_per_step)
+extern long g_wl_launches;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...) do { ++g_wl_launches; kern<<<(grid), (block), (shmem), (stream)>>>(__VA_ARGS__); } while (0)
 
+// Experiment switches (tile heights, chunk lengths, block orders … — tools/*.sh scan them): read from the environment only in a
+// -DWL_EXPERIMENTS build (`tools/build_variant.sh exp "-DWL_EXPERIMENTS" <all sources>`); the product library always takes the default.
+static inline int wl_exp_int(const char* name, int dflt) {
+#ifdef WL_EXPERIMENTS
+  const char* e = getenv(name); return e ? atoi(e) : dflt;
+#else
+  (void)name; return dflt;
+#endif
+}
 // ---- grid helpers (host + device) -------------------------------------------------------------
 struct GridX {  // wl_grid + precomputed strides, passed by value to kernels
   int D, nx, ny, nz, k0, k1, gk, gnz;
@@ -73,7 +87,7 @@ static inline int wl_red_slots(const GridX& g, int nplanes) { long by = WL_REDPA
 // up to 32 planes, shorter on small grids so that a launch still has a few thousand workgroups.
 static inline int wl_march_chunk(const GridX& g, int nplanes) {
   const long bp = 8L * wl_strip_blocks(g);
-  static const long cap = [] { const char* e = getenv("WL_MARCH_CHUNK_CAP"); const long v = e ? atol(e) : 32; return v >= 1 ? v : 32; }();   // experiments only
+  static const long cap = [] { const long v = wl_exp_int("WL_MARCH_CHUNK_CAP", 32); return v >= 1 ? v : 32; }();   // experiments only
   long c = (long)nplanes * bp / 4096; if (c > cap) c = cap; if (c < 1) c = 1;
   while ((nplanes + c - 1) / c * bp > 65536 && c < nplanes) c++;      // per-workgroup partials must fit the reduction workspace
   return (int)c;

@@ -344,7 +344,7 @@ int conv_tile(const float* u_adv, const GridX& g, float nu, int scheme, int ka, 
   const int ntiles = ((g.nx - 2 + CT_CX - 1) / CT_CX) * ((g.ny - 2 + CT_CY - 1) / CT_CY);
   const int per = (ntiles + 7) >> 3;
   const int np = kb - ka;
-  static const int envc = getenv("WL_CT_CHUNK") ? atoi(getenv("WL_CT_CHUNK")) : 0;
+  static const int envc = wl_exp_int("WL_CT_CHUNK", 0);
   int zc = g_convt_chunk > 0 ? g_convt_chunk : envc;
   if (zc <= 0) { long t = (long)np * ntiles / 1024; zc = (int)(t < 5 ? 5 : (t > 64 ? 64 : t)); }   // ≈1024 workgroups (512 resident); small boxes: short chunks (128³: 0.62 -> 0.58 ms/step with 5 planes instead of 16)
   if (g_convt_min == 0 && !g_convt_chunk && !envc) zc = 5;   // tests: several chunks on a small box

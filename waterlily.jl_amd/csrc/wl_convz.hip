@@ -152,7 +152,7 @@ bool conv_z_ok(const GridX& g, unsigned per) { return g.D == 3 && per == 0 && g.
 // conv_diff!(f,u,…) [+ BDIM! NoBody when u0/mu0/u_out are given]; the Q1 ghost-plane write of Φ is done by the caller
 int conv_diff_z(float* f, const float* u_adv, const float* u0, const float* mu0, float* u_out, const GridX& g, float nu, int scheme, float dt, float pre, float post, hipStream_t s) {
   static int ty_sel = -1;
-  if (ty_sel < 0) { const char* e = getenv("WL_CONVZ_TY"); ty_sel = e ? atoi(e) : 4; if (ty_sel != 4 && ty_sel != 8 && ty_sel != 16) ty_sel = 4; }
+  if (ty_sel < 0) { ty_sel = wl_exp_int("WL_CONVZ_TY", 4); if (ty_sel != 4 && ty_sel != 8 && ty_sel != 16) ty_sel = 4; }
   const int TY = ty_sel;
   int kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0, klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1;
   const int ntx = (g.nx + CZ_X - 2) / (CZ_X - 1), nty = (g.ny + TY - 2) / (TY - 1), nt = ntx * nty, per8 = (nt + 7) >> 3;

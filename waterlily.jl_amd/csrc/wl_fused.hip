@@ -288,7 +288,7 @@ bool gsrb_fused_ok(const GridX& g, unsigned per, bool dist) {
 static int zchunk_for(const GridX& g, int H) {
   const int nt = ztile_count(g.nx, g.ny, H);
   const int np = g.k1 - g.k0;
-  static const int zmin_env = getenv("WL_ZC_MIN") ? atoi(getenv("WL_ZC_MIN")) : 0;
+  static const int zmin_env = wl_exp_int("WL_ZC_MIN", 0);
   if ((long)nt * ((np + 31) / 32) >= 2048) {   // many rounds of workgroups: long marches (the pipeline warm-up costs 2H-1 planes per chunk)
     const int chunks = (1536 + nt - 1) / nt;
     int zc = (np + chunks - 1) / chunks; if (zc < 16) zc = 16; if (zc > np) zc = np;

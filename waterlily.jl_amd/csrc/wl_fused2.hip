@@ -35,7 +35,7 @@ int g_pro_fast = 1;   // bit 1 of gsrb_pair_enable: register-window prolongation
 #undef WL_PT_Y
 #undef WL_PNS
 
-static int pair_min_nx() { static const int v = getenv("WL_PAIR_MIN_NX") ? atoi(getenv("WL_PAIR_MIN_NX")) : 34; return v; }   // smallest level width of the pair kernels (34: 256³ 1.81 -> 1.78 ms/step against the one-cell kernels on the 34-wide level; tools/minnx_gate.sh)
+static int pair_min_nx() { static const int v = wl_exp_int("WL_PAIR_MIN_NX", 34); return v; }   // smallest level width of the pair kernels (34: 256³ 1.81 -> 1.78 ms/step against the one-cell kernels on the 34-wide level; tools/minnx_gate.sh)
 namespace wl {
 void gsrb_pair_enable(int on) { g_pair_on = on & 1; g_pro_fast = (on & 2) == 0; }
 // geometry: even nx (float2), tiles not mostly empty, 32-bit offsets; a z-slab needs 3 ghost planes per side (kernel B's halo)
@@ -47,9 +47,9 @@ bool gsrb_pair_ok(const GridX& g, const ConstL& cl) { return cl.on && gsrb_pair_
 bool gsrb_pair_ok_range(const GridX& g, const ConstL& cl) { GridX h = g; if (h.k1 - h.k0 < 8) h.k1 = h.k0 + 8; return g.k1 > g.k0 && gsrb_pair_ok(h, cl); }
 // 16-row tiles where the 32-row tiling cannot fill the chip for many rounds (WL_PAIR_ROWS=16|32 forces one: experiments)
 static bool rows16(const GridX& g, int kernel = 0) {   // kernel: 1 = A, 2 = B (experiments: WL_PAIR_ROWS_A / WL_PAIR_ROWS_B force one kernel's tile height)
-  static const int force_all = getenv("WL_PAIR_ROWS") ? atoi(getenv("WL_PAIR_ROWS")) : 0;
-  static const int force_a = getenv("WL_PAIR_ROWS_A") ? atoi(getenv("WL_PAIR_ROWS_A")) : 0;
-  static const int force_b = getenv("WL_PAIR_ROWS_B") ? atoi(getenv("WL_PAIR_ROWS_B")) : 0;
+  static const int force_all = wl_exp_int("WL_PAIR_ROWS", 0);
+  static const int force_a = wl_exp_int("WL_PAIR_ROWS_A", 0);
+  static const int force_b = wl_exp_int("WL_PAIR_ROWS_B", 0);
   const int force = (kernel == 1 && force_a) ? force_a : ((kernel == 2 && force_b) ? force_b : force_all);
   if (force == 16) return true;
   if (force == 32) return false;

@@ -1020,7 +1020,7 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
 }
 // linear block order (wl_tile_lin), one plane per block: bit 0 = the first projection tail (1.04 -> 0.875 ms at 512³), bit 1 = the second (project_cfl: SLOWER, 1.33 -> 1.55 ms — its
 // 13 loads per cell make it L1/L2-bound, not HBM-bound; the integer atomics are not the cause, profiles/r03_experiments.md).  Default 1.
-static int tail_lin(int bit) { static const int v = getenv("WL_TAIL_LIN") ? atoi(getenv("WL_TAIL_LIN")) : 1; return (v >> bit) & 1; }
+static int tail_lin(int bit) { static const int v = wl_exp_int("WL_TAIL_LIN", 1); return (v >> bit) & 1; }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold) {
   const int lin = tail_lin(0) && g.D == 3;
   const int zc = lin ? 1 : wl_march_chunk(g, g.nz);

@@ -119,17 +119,17 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
   const int np = g.k1 - g.k0;
   // 16-row tiles (512 threads, four resident workgroups per CU): measured faster at every size (tools/rj_rows.sh: head 0.30 -> 0.275 ms/step at 256³,
   // 1.63 -> 1.55 at 512³ — the latency hiding of four workgroups outweighs the 12 % more halo traffic); WL_RJ_ROWS=32 brings the 1024-thread tiles back
-  static const int rows_env = getenv("WL_RJ_ROWS") ? atoi(getenv("WL_RJ_ROWS")) : 0;
+  static const int rows_env = wl_exp_int("WL_RJ_ROWS", 0);
   const bool r16 = rows_env != 32;
   const int ntiles = r16 ? rj16::rj_tiles(g) : rj32::rj_tiles(g), per = (ntiles + 7) >> 3;
   const long SX = r16 ? rj16::rj_slots_per_xcd() : rj32::rj_slots_per_xcd();
-  static const int envc = getenv("WL_RJ_CHUNK") ? atoi(getenv("WL_RJ_CHUNK")) : 0;
+  static const int envc = wl_exp_int("WL_RJ_CHUNK", 0);
   int zc = envc;
   if (zc <= 0) {
     // equal workgroups run in rounds of 32 CUs × the resident workgroups per CU on every XCD (tile ranges are dealt XCD by XCD): minimise
     // rounds × (planes per chunk + the 2 warm-up planes), with a balance penalty for few rounds — as wl_fused2's zchunk2.  The former fixed target of
     // 3072 workgroups gave 6.2 rounds at 512³, i.e. a seventh, almost empty one.
-    static const int chforce = getenv("WL_RJ_CHUNKS") ? atoi(getenv("WL_RJ_CHUNKS")) : 0;     // experiments: number of chunks
+    static const int chforce = wl_exp_int("WL_RJ_CHUNKS", 0);     // experiments: number of chunks
     double best = -1.0; zc = np;
     for (int chunks = 1; chunks <= np; chunks++) {
       const int z = (np + chunks - 1) / chunks;

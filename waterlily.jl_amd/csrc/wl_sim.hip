@@ -227,6 +227,17 @@ __global__ void k_exit_facesum(GridX g, const float* __restrict__ u, double* __r
     if (mode == 0) out[0] = (double)mean; else out[1] = (double)(mean - (float)out[0]);
   }
 }
+// The x-exit face of the normal component (Julia index N of u[:,:,:,1], every row and plane): with the convective exit BC! leaves it alone
+// (saveexit, src/core.jl:207) and only exitBC! rewrites its interior rows — so when the roles of the velocity buffers rotate instead of
+// `u⁰ .= u` being a copy, the face has to travel with the role.
+template <int D>
+__global__ void k_copy_exit_face(GridX g, float* __restrict__ dst, const float* __restrict__ src) {
+  const long cnt = (long)g.ny * (D == 3 ? g.nz : 1);
+  const long q = (long)blockIdx.x * WL_BLOCK + threadIdx.x;
+  if (q >= cnt) return;
+  const long o = (g.nx - 1) + q * g.sy;      // (rows are contiguous over planes: j + k·ny)
+  dst[o] = src[o];
+}
 // z-slab variant: every rank sums its owned planes of the face (res_d[slot], summed over ranks by combine_results), then
 // k_exit_mean turns the global sum into the mean exactly as above (float division by the global face size)
 template <int D>
@@ -376,6 +387,7 @@ struct wl_sim {
     return wl::bdim(u, u0, f, nullptr, mu0, nullptr, G, dt.back(), pre, post, s);
   }
   int exit_bc(hipStream_t s);
+  int copy_exit_face(float* dst, const float* src, hipStream_t s);
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
     if (hybrid_ok()) {
       WL_TRY(conv_bdim_body(u0, u, 0.f, 1.f, s));
@@ -411,6 +423,7 @@ struct wl_sim {
           WL_TRY(wl::conv_q1(sigma, u, G, d.nu, d.perdir_mask, d.scheme, s));
         } else WL_TRY(conv_fused(u, us, 1.f, 0.5f, s)); }
       std::swap(u, us);
+      if (d.exitBC) WL_TRY(copy_exit_face(u, us, s));   // BC!(…,saveexit) keeps the predictor's exit face
       return bc_u(s);
     }
     { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u, s)); }
@@ -421,6 +434,8 @@ struct wl_sim {
   bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
   bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
   long n_resjac = 0, n_resjac_redo = 0;   // how often the fused head stood / had to be redone because the mean shift was due
+  int resjac_redo_run = 0;                // consecutive redos: after WL_RESJAC_BACKOFF of them the fused head is switched off for this handle
+  bool resjac_backoff = false;            // (a flow whose residual needs the mean shift on every solve would pay launch + sync + two-kernel path each time); re-armed by update!
   int p_shell = -1;          // ghost shell of p / the spare pressure array: -1 unknown (check before the next fused head), 0 all +0, 1 something else, 2 caller-owned p (never assumed)
   bool use_fuse_cfl = true;  // the corrector's projection tail also produces CFL's σ and max(σ)
   bool cfl_done = false;
@@ -433,7 +448,7 @@ struct wl_sim {
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
       bool head_done = false;
-      if (use_resjac && !store_f && !comm && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl)) {
+      if (use_resjac && !resjac_backoff && !d.exitBC && !store_f && !comm && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl)) {   // (exitBC: the convective exit leaves a net flux imbalance to the solver's tolerance — the shift is usually due)
         // head + the V-cycle's first Jacobi!(fine) in one launch, assuming residual!'s mean shift is not due (wl_resjac.hip); Σr decides
         { ProfScope pr(WL_PROF_RESIDUAL, s);
           // p's and the spare's ghost cells are +0 unless someone wrote them from outside (checked once after a pointer to p was handed out): no shell pass then
@@ -444,8 +459,11 @@ struct wl_sim {
         if (std::fabs(sm) <= 2.f * 1.1920929e-7f && !resjac_force_redo) {                                       // src/Poisson.jl:96: no shift — the fused results stand
           std::swap(p, ps); l0.x = p;
           std::swap(l0.r, l0.eps);
-          mg->jacobi0_done = true; head_done = true; n_resjac++;
-        } else n_resjac_redo++;                                                            // shift due: the inputs are untouched, take the two-kernel path
+          mg->jacobi0_done = true; head_done = true; n_resjac++; resjac_redo_run = 0;
+        } else {                                                                           // shift due: the inputs are untouched, take the two-kernel path
+          n_resjac_redo++;
+          if (!resjac_force_redo && ++resjac_redo_run >= 3) resjac_backoff = true;
+        }
       }
       if (!head_done) {
         ProfScope pr(WL_PROF_RESIDUAL, s);
@@ -486,7 +504,7 @@ struct wl_sim {
     ProfScope pstep(WL_PROF_STEP, s);
     // u⁰ .= u ; scale_u!(a,0): when the handle owns both arrays the copy is a pointer swap — the predictor overwrites
     // every interior cell of u (BDIM! with pre=0) and BC! every ghost cell, so nothing of the old u survives anyway.
-    if (swap_ok) std::swap(u, u0);   // (an exchange still in flight belongs to the array that is now u⁰ — the predictor's advecting field)
+    if (swap_ok) { std::swap(u, u0); if (d.exitBC) WL_TRY(copy_exit_face(u, u0, s)); }   // (an exchange still in flight belongs to the array that is now u⁰ — the predictor's advecting field)
     else { WL_TRY(sync_u(s)); WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s)); }   // u⁰ .= u
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s));
@@ -495,6 +513,11 @@ struct wl_sim {
     return cfl(s);
   }
 };
+int wl_sim::copy_exit_face(float* dst, const float* src, hipStream_t s) {
+  const long cnt = (long)G.ny * (G.D == 3 ? G.nz : 1);
+  DSEL(G.D, k_copy_exit_face, dim3((unsigned)((cnt + WL_BLOCK - 1) / WL_BLOCK)), dim3(WL_BLOCK), 0, s, G, dst, src);
+  WL_LAUNCH_CHECK(); return 0;
+}
 int wl_sim::exit_bc(hipStream_t s) {
   if (comm) {   // z-slabs: the exit face is shared by all ranks — global means from per-rank sums (one 128-byte all-gather each)
     if (!exit_sc) WL_HIP(hipMalloc((void**)&exit_sc, 2 * sizeof(double)));
@@ -566,7 +589,8 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   const size_t sz[8] = {nc * D, nc * D, nc * D, nc, nc, nc * D, nc * D, nc * D * D};
   size_t total = 0;
   const bool none = !desc->u && !desc->u0, all3 = desc->u && desc->u0 && desc->us;
-  const bool want_us = none && !desc->us && !desc->exitBC;   // spare velocity array of the out-of-place fused kernels (handle-owned)
+  const bool rot_ok = !desc->exitBC || !slab;               // convective exit: the buffers rotate on a single domain only (the exit face travels with the role, k_copy_exit_face)
+  const bool want_us = none && !desc->us && rot_ok;         // spare velocity array of the out-of-place fused kernels (handle-owned)
   if (want_us) total += nc * D;
   total += nc;   // ps
   for (int q = 0; q < 8; q++) if (!given[q] && !(q == 7 && !desc->has_body) && !(q == 5 && !desc->has_body)) total += sz[q];
@@ -578,11 +602,11 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     else { *ptrs[q] = pcur; pcur += sz[q]; }
   }
   if (want_us) { s->us = pcur; pcur += nc * D; }
-  else if (desc->us && (none || all3) && !desc->exitBC) s->us = desc->us;   // caller-owned spare: the roles of {u,u0,us} rotate (wlhip.h)
+  else if (desc->us && (none || all3) && rot_ok) s->us = desc->us;   // caller-owned spare: the roles of {u,u0,us} rotate (wlhip.h)
   s->ps = pcur; pcur += nc;
   s->dt.assign(1, desc->dt0);
   if (desc->p) s->p_shell = 2;     // a caller-owned p can be written behind the library's back: its ghost shell is always scaled
-  s->swap_ok = (none || all3) && !desc->exitBC;
+  s->swap_ok = (none || all3) && rot_ok;
   // μ₀ = 1 with BC!(μ₀,0)   src/Flow.jl:144-145  (only when the handle owns μ₀; a caller-owned μ₀ is taken as is)
   if (!desc->mu0) {
     int rc = wl::fill(s->mu0, 1.f, nc * D, 0); const float zero[3] = {0, 0, 0};
@@ -664,7 +688,17 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
-int wl_sim_update(wl_sim* s, void* st) { WL_TRY(s->refresh_body_mask(wl_stream(st))); return s->mg->update(wl_stream(st)); }
+int wl_sim_update(wl_sim* s, void* st) { s->resjac_backoff = false; s->resjac_redo_run = 0; WL_TRY(s->refresh_body_mask(wl_stream(st))); return s->mg->update(wl_stream(st)); }
+
+long wl_launch_count(void) { return g_wl_launches; }
+int wl_sim_counter(wl_sim* s, const char* name, long* out) {
+  WL_CHECK(s && name && out, "bad argument");
+  const std::string n(name);
+  if (n == "resjac") { *out = s->n_resjac; return 0; }
+  if (n == "resjac_redo") { *out = s->n_resjac_redo; return 0; }
+  if (n == "resjac_backoff") { *out = s->resjac_backoff ? 1 : 0; return 0; }
+  wl_set_error("unknown counter " + n); return WL_EINVAL;
+}
 int wl_sim_set_forcing(wl_sim* s, const float* U1, const float* a0, const float* a1) {
   const int D = s->d.D;
   if (U1) for (int c = 0; c < D; c++) s->d.uBC[c] = U1[c];

@@ -44,14 +44,16 @@ mutable struct HipArray{T,N} <: AbstractArray{T,N}
     ptr::Ptr{T}
     dims::NTuple{N,Int}
     owned::Bool
+    bodied::Bool          # set on flow.μ₁ by measure! with a real body (see has_body): a flag on the OBJECT — a dictionary keyed by the array would hash
+                          # its contents through scalar getindex (one wl_d2h per element) on every lookup
     function HipArray{T,N}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N}
         T === Float32 || error("the HIP path computes in Float32 (got $T)")
         p = Ref{Ptr{Cvoid}}()
         chk(ccall((:wl_malloc, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Csize_t), p, max(prod(dims), 1) * sizeof(T)))
-        a = new{T,N}(Ptr{T}(p[]), dims, true)
+        a = new{T,N}(Ptr{T}(p[]), dims, true, false)
         finalizer(x -> (x.owned && ccall((:wl_free, libwlhip), Cint, (Ptr{Cvoid},), x.ptr); nothing), a)   # Julia owns lifetimes (SURVEY §8b)
     end
-    HipArray{T,N}(p::Ptr{T}, dims::NTuple{N,Int}) where {T,N} = new{T,N}(p, dims, false)   # non-owning view of a library array
+    HipArray{T,N}(p::Ptr{T}, dims::NTuple{N,Int}) where {T,N} = new{T,N}(p, dims, false, false)   # non-owning view of a library array
 end
 HipArray{T}(::UndefInitializer, dims::NTuple{N,Int}) where {T,N} = HipArray{T,N}(undef, dims)
 HipArray{T}(::UndefInitializer, dims::Int...) where {T} = HipArray{T,length(dims)}(undef, dims)
@@ -119,7 +121,9 @@ Base.copyto!(dest::HipArray, bc::Base.Broadcast.Broadcasted{<:Base.Broadcast.Abs
 struct HipStyle <: Base.Broadcast.AbstractArrayStyle{Any} end
 HipStyle(::Val) = HipStyle()
 Base.Broadcast.BroadcastStyle(::Type{<:HipArray}) = HipStyle()
-Base.Broadcast.BroadcastStyle(::HipStyle, ::Base.Broadcast.AbstractArrayStyle) = HipStyle()
+# (HipArray with scalars / host arrays: Base's own rule BroadcastStyle(a::AbstractArrayStyle{Any}, ::DefaultArrayStyle) = a already returns HipStyle();
+#  the explicit method below is strictly more specific than it — a method over ::AbstractArrayStyle in the second slot would be ambiguous with it)
+Base.Broadcast.BroadcastStyle(::HipStyle, ::Base.Broadcast.DefaultArrayStyle) = HipStyle()
 Base.copy(bc::Base.Broadcast.Broadcasted{HipStyle}) = HipArray(Base.Broadcast.materialize(Base.Broadcast.Broadcasted(bc.f, map(hostarg, bc.args))))
 
 # ---- reductions the path uses (src/Poisson.jl:95,189-191; src/Flow.jl:236; src/core.jl:229,231) -----------------------------
@@ -294,19 +298,18 @@ struct WlSimDesc
     u::Ptr{Cfloat}; u0::Ptr{Cfloat}; f::Ptr{Cfloat}; p::Ptr{Cfloat}; sigma::Ptr{Cfloat}; V::Ptr{Cfloat}; mu0::Ptr{Cfloat}; mu1::Ptr{Cfloat}; us::Ptr{Cfloat}
 end
 # flows that went through measure! with a real body: BDIM! needs μ₁ and V there (NoBody: μ₁ ≡ 0, V ≡ 0 are never read)
-const BODIED = WeakKeyDict{Any,Bool}()
-has_body(a::HFlow) = get(BODIED, a.μ₁, false)
+has_body(a::HFlow) = a.μ₁.bodied      # (a field of the μ₁ object: identity, O(1), no device access)
 function composite!(a::HFlow{D}, b::HipMultiLevel) where {D}
     if b.sim != C_NULL && (b.flowkey != objectid(a) || b.has_body != has_body(a))
         chk(ccall((:wl_sim_destroy, libwlhip), Cint, (Ptr{Cvoid},), b.sim)); b.sim = C_NULL
     end
     b.sim != C_NULL && return b.sim
     @assert b.x === a.p && b.L === a.μ₀ && b.z === a.σ "the composite time step needs the MultiLevelPoisson built on this flow's p, μ₀, σ"
-    uBC = a.uBC isa Tuple ? pad3(a.uBC) : (0f0, 0f0, 0f0)
+    uBC = a.uBC isa Tuple ? pad3(a.uBC) : pad3(ntuple(i -> Float32(a.uBC(i, ntuple(_ -> 0f0, D), 0f0)), D))     # (a Function here is uniform in x: mom_step! checked)
     N = size(a.p) .- 2
     spare = (b.spare === nothing || size(b.spare) != size(a.u)) ? similar(a.u) : b.spare
     d = Ref(WlSimDesc(D, ntuple(i -> i <= D ? Int32(N[i]) : Int32(1), 3), uBC, a.ν, a.Δt[end], pmask(a.perdir), Int32(a.exitBC), scheme(a.λ), Int32(has_body(a)),
-                      a.u.ptr, a.u⁰.ptr, a.f.ptr, a.p.ptr, a.σ.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, a.exitBC ? Ptr{Cfloat}(C_NULL) : spare.ptr))
+                      a.u.ptr, a.u⁰.ptr, a.f.ptr, a.p.ptr, a.σ.ptr, a.V.ptr, a.μ₀.ptr, a.μ₁.ptr, spare.ptr))   # (exitBC flows too: `u⁰ .= u` stays a pointer rotation; the fused CFL tail is skipped by the library itself)
     h = Ref{Ptr{Cvoid}}()
     chk(ccall((:wl_sim_create_on, libwlhip), Cint, (Ref{Ptr{Cvoid}}, Ref{WlSimDesc}, Ptr{Cvoid}), h, d, b.handle))
     b.sim = h[]; b.spare = spare; b.flowkey = objectid(a); b.has_body = has_body(a)
@@ -317,16 +320,37 @@ simfield(sim, name) = ccall((:wl_sim_field, libwlhip), Ptr{Cfloat}, (Ptr{Cvoid},
 # mom_step!(a,b) src/Flow.jl:156-167 as ONE library call: the fused kernels (conv_diff!+BDIM!, div+residual!, blocked smoother,
 # projection+CFL) of wl_sim_mom_step.  Closures (uBC(i,x,t), g(i,x,t), udf) cannot cross the C ABI: such flows take the reference's
 # own mom_step! over the leaf methods above.
+# uBC(i,x,t) / g(i,x,t) that do not depend on x are tabulated per step (D numbers each) and keep the composite path: wl_sim_set_forcing
+# takes uBC(i,t₁) and g(i,t)+dU(i,t)/dt at t₀ and t₁ (accelerate!, src/Flow.jl:69-73; dU/dt by ForwardDiff as in the reference).  A closure is
+# taken to be uniform when it returns the same value at three probe points of the domain; anything else takes the leaf-op path.
+function uniform_in_x(f::Function, D, N, t)
+    xs = (ntuple(_ -> 0f0, D), ntuple(i -> Float32(N[i]) / 2, D), ntuple(i -> Float32(N[i]) * 0.83f0 + 0.5f0, D))
+    all(i -> f(i, xs[1], t) == f(i, xs[2], t) == f(i, xs[3], t), 1:D)
+end
+uniform_in_x(::Nothing, D, N, t) = true
+uniform_in_x(f, D, N, t) = true                      # tuples
+dUdt(f::Function, i, x, t) = Float32(WaterLily.ForwardDiff.derivative(τ -> f(i, x, τ), t))     # as src/Flow.jl:72-73 (WaterLily `using`s ForwardDiff, src/core.jl:245)
+dUdt(f, i, x, t) = 0f0
+function set_forcing!(sim, a::HFlow{D}) where {D}
+    (a.uBC isa Function || a.g !== nothing) || return
+    N = size(a.p) .- 2; x0 = ntuple(_ -> 0f0, D)
+    t1 = sum(a.Δt); t0 = t1 - a.Δt[end]                                              # src/Flow.jl:157
+    U1 = a.uBC isa Function ? pad3(ntuple(i -> Float32(a.uBC(i, x0, t1)), D)) : pad3(a.uBC)
+    acc(t) = pad3(ntuple(i -> (a.g === nothing ? 0f0 : Float32(a.g(i, x0, t))) + dUdt(a.uBC, i, x0, t), D))
+    chk(ccall((:wl_sim_set_forcing, libwlhip), Cint, (Ptr{Cvoid}, Ref{NTuple{3,Cfloat}}, Ref{NTuple{3,Cfloat}}, Ref{NTuple{3,Cfloat}}), sim, Ref(U1), Ref(acc(t0)), Ref(acc(t1))))
+end
 function mom_step!(a::HFlow{D}, b::HipMultiLevel; udf=nothing, kwargs...) where {D}
-    if a.uBC isa Function || a.g !== nothing || udf !== nothing
-        return invoke(mom_step!, Tuple{AbstractFlow,AbstractPoisson}, a, b; udf, kwargs...)
+    N = size(a.p) .- 2; tnow = sum(a.Δt)
+    if udf !== nothing || !(uniform_in_x(a.uBC, D, N, tnow) && uniform_in_x(a.g, D, N, tnow))
+        return invoke(mom_step!, Tuple{AbstractFlow,AbstractPoisson}, a, b; udf, kwargs...)      # position-dependent closures: the reference's own mom_step! over the leaf methods
     end
     sim = composite!(a, b)
+    set_forcing!(sim, a)
     chk(ccall((:wl_sim_set_dt_last, libwlhip), Cint, (Ptr{Cvoid}, Cfloat), sim, a.Δt[end]))    # the host owns flow.Δt (src/Flow.jl:127)
     chk(ccall((:wl_sim_mom_step, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), sim, C_NULL))
     # the step permuted the roles of {u, u⁰, spare}: re-point the three objects (same buffers, same owners)
     a.u.ptr = simfield(sim, "u"); a.u⁰.ptr = simfield(sim, "u0")
-    b.spare !== nothing && !a.exitBC && (b.spare.ptr = simfield(sim, "us"))
+    b.spare !== nothing && (b.spare.ptr = simfield(sim, "us"))
     push!(a.Δt, ccall((:wl_sim_dt_last, libwlhip), Cfloat, (Ptr{Cvoid},), sim))                   # push!(a.Δt,CFL(a))
     hist = Vector{Int16}(undef, length(b.n) + 2)                                                    # pois.n: two solves per step
     k = ccall((:wl_mg_history, libwlhip), Cint, (Ptr{Cvoid}, Ptr{Int16}, Cint), b.handle, hist, Cint(length(hist)))
@@ -357,7 +381,7 @@ function measure!(a::HFlow{N}, body::AbstractBody; t=zero(Float32), ϵ=1) where 
     sh = HostShadow{N,T}(zeros(T, size(a.p)), zeros(T, size(a.σ)), zeros(T, size(a.V)), ones(T, size(a.μ₀)), zeros(T, size(a.μ₁)), a.exitBC, a.perdir)
     measure!(sh, body; t, ϵ)                       # the reference's generic method: sh is not an HFlow
     copyto!(a.σ, sh.σ); copyto!(a.V, sh.V); copyto!(a.μ₀, sh.μ₀); copyto!(a.μ₁, sh.μ₁)
-    BODIED[a.μ₁] = true
+    a.μ₁.bodied = true
     nothing
 end
 # closed-form shapes on the device (SURVEY row f1)
@@ -381,7 +405,7 @@ wlbody(b::HipBody, D, t) = Ref(WlBody(b.kind, pad3(at(b.c, t)), b.R, ntuple(i ->
 function measure!(a::HFlow{D}, body::HipBody; t=zero(Float32), ϵ=1) where {D}
     chk(ccall((:wl_measure_body, libwlhip), Cint, (Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ptr{Cfloat}, Ref{WlGrid}, Ref{WlBody}, Cfloat, Cint, Cuint, Ptr{Cvoid}),
               a.σ.ptr, a.μ₀.ptr, a.μ₁.ptr, a.V.ptr, sgrid(a.σ), wlbody(body, D, t), Cfloat(ϵ), Cint(a.exitBC), pmask(a.perdir), C_NULL))
-    BODIED[a.μ₁] = true
+    a.μ₁.bodied = true
     nothing
 end
 # pressure_force / viscous_force (src/Metrics.jl:116-133,140-154): Float64 sums on device, flow.f is not used as scratch

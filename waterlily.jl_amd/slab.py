@@ -294,6 +294,7 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
     dist.barrier()
     torch.cuda.synchronize()
     cs0 = comm_stats(comm)
+    l0 = int(lib().wl_launch_count())
     t0 = time.perf_counter()
     for _ in range(args.steps):
         sim.mom_step_()
@@ -301,6 +302,7 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
     dist.barrier()
     el = time.perf_counter() - t0
     cs1 = comm_stats(comm)
+    launches_per_step = (int(lib().wl_launch_count()) - l0) / args.steps
     t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
@@ -323,7 +325,7 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"3D Taylor-Green vortex {N}^3 Float32, wall-bounded, Re=1600, NoBody, remeasure=false, {world} z-slabs",
                           "size": N, "parallelism": f"zslab{world}", "transport": type(comm).__name__, "mean_pois_n": float(sum(pn)) / max(1, len(pn)),
-                          "dt_last": float(sim.dt[-1]),
+                          "dt_last": float(sim.dt[-1]), "launches_per_step_rank0": launches_per_step,
                           "comm_per_step_rank0": {k: (cs1[k] - cs0[k]) / args.steps for k in cs1}},
                "roofline": roof, "cpu_baseline": None}
         if cpu_baseline is not None:      # outside the timed region; the other ranks wait at the barrier below
