@@ -140,7 +140,7 @@ def kernel_config_sha():
     return h.hexdigest()[:16]
 
 
-def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
+def build_roofline(prof, ncell, const0, kind0, N, use_traffic, xdefer=None):
     """`roofline` object for the finest-level smooth! of THIS rank (ncell = the cells its launches process).
 
     achieved / frac   : the kernels' OWN algorithmic bytes (what each launch must move, BYTES_KERNEL) ÷ HIP-event time ÷ 8 TB/s
@@ -154,7 +154,8 @@ def build_roofline(prof, ncell, const0, kind0, N, use_traffic):
     pro_fused = prof["prolong_increment"]["launches"] == 0       # the V-cycle's prolongate!+increment! is folded into kernel A
     pair_ms = ka_ms + kb_ms
     bytes_op = BYTES_OP_GSRB + (BYTES_OP_PROLONG_INC if pro_fused else 0.0)
-    x_deferred = bool(pro_fused and const0 and kind0 == 2 and os.environ.get("WL_OPT_xdefer", "1") != "0")
+    # which kernel applied the V-cycle's x += ω·x_c↓: the library's own decision (wl_sim_counter "xdefer"), not an assumption
+    x_deferred = bool(pro_fused and const0 and kind0 == 2 and (xdefer == 1 if xdefer is not None else True))
     bytes_a = BYTES_KERNEL[(("A_pro_xd" if x_deferred else "A_pro") if pro_fused else "A", const0)]
     bytes_b = BYTES_KERNEL[("B_xd" if x_deferred else "B", const0)]
     gbs = lambda by, ms: by * ncell / (ms * 1e-3) / 1e9
@@ -292,7 +293,7 @@ def main():
     check(lib.wl_prof_enable(0))
     ncell = float(N) ** 3
     pn = sim.pois_n[n_warm:]
-    roof = build_roofline(prof, ncell, bool(sim.const_levels()[0]), sim.smoother_kinds()[0], N, use_traffic=True)
+    roof = build_roofline(prof, ncell, bool(sim.const_levels()[0]), sim.smoother_kinds()[0], N, use_traffic=True, xdefer=counter("xdefer"))
     out = {
         "metric": "cells*steps/sec (3D TGV) ; smoother HBM GB/s vs peak", "value": ncell * args.steps / el, "unit": "cells*steps/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,

@@ -142,7 +142,8 @@ int wl_mg_smoother_kind(const wl_mg* mg, int level);   /* how smooth! runs on th
 int wl_mg_set_fused(wl_mg* mg, int on);   /* bit0 (default 1): temporally blocked smoother on eligible levels, 0: one kernel per pass;
                                              bit1: do not store the final ϵ (scratch of the reference that nothing reads again);
                                              bit2: no pair kernels; bit3: no single-launch coarse tail; bit4: no z-split on body levels;
-                                             bit5: coarse tail in global memory instead of LDS; bit6: x increment of the prolongation not deferred to kernel B */
+                                             bit5: coarse tail in global memory instead of LDS (process-wide switch); bit6: x increment of the prolongation not deferred to kernel B;
+                                             bit7: z-slabs: the smoother's deep r exchange is not overlapped with kernel A's interior planes */
 /* solver!(ml;tol,itmx): returns iterations in *host_n and the last L₁/L∞; appends to the n history. */
 int wl_mg_solve(wl_mg* mg, double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, void* stream);
 int wl_mg_history(const wl_mg* mg, int16_t* host_out, int cap);                        /* pois.n :66 */
@@ -175,7 +176,9 @@ typedef struct wl_sim_desc {
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc);
 /* the same on an EXISTING multigrid handle (wl_mg_create on desc->p, desc->mu0, desc->sigma): the Simulation constructor of the
    reference builds the AbstractPoisson first (pois_ctor, src/WaterLily.jl:96-105) and mom_step!(flow,pois) receives both.  The wl_mg
-   stays the caller's (destroy the wl_sim first). */
+   stays the caller's (destroy the wl_sim first).  Side effects on the adopted handle: the final ϵ of smooth! is no longer stored
+   (wl_mg_set_fused bit1 — scratch nothing on the time-step path reads).  WL_EINVAL if the handle was not built on desc's p, mu0, sigma or
+   with a different perdir mask. */
 int wl_sim_create_on(wl_sim** out, const wl_sim_desc* desc, wl_mg* mg);
 int wl_sim_destroy(wl_sim* s);
 float* wl_sim_field(wl_sim* s, const char* name);       /* "u","u0","f","p","sigma","V","mu0","mu1","us" (current roles) */
@@ -200,8 +203,12 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0)
    "xdefer"[1] pair smoother: the V-cycle's x += ω·x_c↓ is applied by kernel B together with its own increment (x makes one round trip per smooth!)
    "tail_lds"[1] the single-launch coarse tail keeps r, x, ϵ of its levels in LDS (0: in global memory)
-   "body_tile"[1] with a body: conv_diff!+BDIM! on the body-free plane ranges through the tiled NoBody kernel ("convt") */
+   "body_tile"[1] with a body: conv_diff!+BDIM! on the body-free plane ranges through the tiled NoBody kernel ("convt")
+   "itmx"[32] solver!'s iteration cap `itmx` (src/MultiLevelPoisson.jl:108) */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
+/* "resjac_min", "convt_min", "convt", "tail_lds", "body_tile", "pair", "jacobi_march", "convm" (and wl_mg_set_fused bits 2 and 5) are PROCESS-wide:
+   they choose between kernels that produce identical bits, for every handle of the process.  wl_reset_process_options() restores their defaults. */
+int wl_reset_process_options(void);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and
    g(i,t)+dU(i,t)/dt at t₀ (predictor) and t₁ (corrector) before each mom_step! (src/Flow.jl:156-167, accelerate! :69-73).
    NULL U1 keeps the boundary velocity; NULL a0 and a1 switches the forcing off. */
@@ -264,6 +271,12 @@ int wl_comm_callbacks_create(wl_comm** out, int rank, int size, void* ctx, wl_se
 /* TEST mode of a ONE-rank communicator: both neighbours are this rank (z-periodic wrap onto itself), so that the transport
  * calls a one-rank run would skip (ncclSend/ncclRecv groups, in-place ncclAllGather, the scalar combine) execute on a one-GPU box */
 int wl_comm_set_loopback(wl_comm* c, int on);
+/* REHEARSAL mode of a ONE-rank RCCL communicator: it reports itself as rank `rank` of `size` — slab geometry, wall logic, exchange pattern and
+ * byte counts are those of that rank in a `size`-GPU run — while the planes it sends to a neighbour come back as its own ghost planes and
+ * all-gathers fill every rank's block with copies of its own.  The flow is not the P-rank flow (the slab sees itself as its neighbours);
+ * what it measures on ONE GPU is the rank's compute per step, its exchange rounds/bytes, and the issue cost of the RCCL calls
+ * (tools/slab_rank_bench.py -> profiles/r03_slab8_rank_compute.json).  Call right after wl_comm_rccl_create (+ _add_async). */
+int wl_comm_set_virtual(wl_comm* c, int rank, int size);
 /* z-periodic domain on z-slabs: the halo exchanges wrap around (rank 0's lower neighbour is the last rank).  wl_sim_create sets it from the
  * descriptor's perdir mask; callback transports get both neighbours on every rank and must address them modulo the size. */
 int wl_comm_set_periodic(wl_comm* c, int on);

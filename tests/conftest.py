@@ -18,3 +18,13 @@ def oracle():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+@pytest.fixture(autouse=True)
+def _process_wide_switches_back_to_default(request):
+    """some implementation switches of libwlhip are process-wide (include/wlhip.h: wl_reset_process_options): a test that moves a size gate
+    must not decide which kernels the next test runs"""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import waterlily_jl_amd as w
+        w.lib().wl_reset_process_options()

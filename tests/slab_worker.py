@@ -104,6 +104,9 @@ def main():
         nu = dims[0] / 1600.0
         sim = slab.SlabSimulation(comm, dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv")
         ref = w.FusedSimulation(dims, (0, 0, 0), dims[0], U=1, nu=nu, ic="tgv") if rank == 0 else None
+        for kv in filter(None, os.environ.get("WL_SLAB_OPTS", "").split(",")):      # e.g. "resjac_min=0": size gates lowered for small test boxes (process-wide switches)
+            k, v = kv.split("=")
+            check(L.wl_sim_set_option(sim._h, k.encode(), int(v)))
         mg = L.wl_sim_pois(sim._h)
         kinds = [L.wl_mg_smoother_kind(mg, l) for l in range(L.wl_mg_nlevels(mg))]
         if rank == 0:
@@ -122,6 +125,9 @@ def main():
                 assert sim.pois_n == ref.pois_n
                 assert abs(float(sim.dt[-1]) - float(ref.dt[-1])) <= 1e-6 * float(ref.dt[-1])
                 assert du < 2e-5 and dp < 2e-4, (du, dp)   # only the reductions' association order differs
+        cnt = C.c_long()
+        check(L.wl_sim_counter(sim._h, b"resjac", C.byref(cnt)))
+        print(f"rank {rank}: fused projection heads on the slab: {cnt.value}", flush=True)
         dist.barrier()
         del sim
         comm.destroy()

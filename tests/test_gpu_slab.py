@@ -25,6 +25,28 @@ def test_small_distributed_slabs_as_on_eight_ranks(n, dims):
     assert kinds and kinds[0].count("2") >= 2, kinds           # pair kernels on at least two distributed levels
 
 
+@pytest.mark.parametrize("n,dims", [(2, "128x64x64"), (4, "128x64x128"), (3, "192x48x96")])
+def test_fused_projection_head_on_slabs_matches_single_domain(n, dims):
+    """the fused projection head (div + x·dt + residual! + first Jacobi!, wl_resjac.hip) on z-slabs: the residual of the neighbour's boundary
+    plane is recomputed from two ghost planes of x and u, Σr / L₁ / L∞ are combined over the ranks before the host decides on residual!'s mean
+    shift, and the Jacobi r exchange of the two-kernel path disappears.  Size gate lowered (the boxes are small); same u, p, pois.n, Δt as the
+    single domain (which runs its own fused head)."""
+    out = run_ranks(n, "gpu_sim", dims, "3", timeout=600, extra_env={"WL_SLAB_OPTS": "resjac_min=0"})
+    for r in range(n):
+        assert f"rank {r}: gpu_sim ok" in out
+        assert f"rank {r}: fused projection heads on the slab: 6" in out          # two solves per step, three steps
+
+
+@pytest.mark.parametrize("n,dims,repl", [(4, "64x32x144", "8"), (2, "64x64x100", "8"), (3, "64x32x120", "16")])
+def test_slab_sizes_that_are_not_P_times_a_power_of_two(n, dims, repl):
+    """nz = 144 on 4 ranks: 36 -> 18 -> 9 planes per rank; nz = 100 on 2: 50 -> 25; nz = 120 on 3: 40 -> 20 -> 10 -> 5.  The level that would get an odd number
+    of planes per rank while still being coarsened in z is replicated instead of distributed (with the replication threshold lowered so that
+    this rule, not the size threshold, decides).  Same u, p, pois.n, Δt as the single domain."""
+    out = run_ranks(n, "gpu_sim", dims, "3", timeout=600, extra_env={"WL_REPLICATE_PLANES": repl})
+    for r in range(n):
+        assert f"rank {r}: gpu_sim ok" in out
+
+
 @pytest.mark.parametrize("n,dims", [(2, "64x32x32"), (4, "48x32x64")])
 def test_slab_exit_bc_with_body_matches_single_domain(n, dims):
     out = run_ranks(n, "gpu_exit", dims, "3", timeout=600)

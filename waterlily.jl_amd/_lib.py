@@ -134,6 +134,7 @@ SIGNATURES = {
     "wl_comm_rccl_available": (i32, []),
     "wl_comm_rccl_add_async": (i32, [P, C.c_char_p]),
     "wl_comm_set_loopback": (i32, [P, i32]),
+    "wl_comm_set_virtual": (i32, [P, i32, i32]),
     "wl_comm_set_periodic": (i32, [P, i32]),
     "wl_comm_halo_async": (i32, [P, P, G, i32, i32, P]),
     "wl_comm_combine_test": (i32, [P, P, P, P]),
@@ -146,6 +147,7 @@ SIGNATURES = {
     "wl_grid_slab": (i32, [G, i32, C.POINTER(C.c_int32), i32, i32, i32]),
     "wl_sim_create_slab": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc), P]),
     "wl_launch_count": (C.c_long, []),
+    "wl_reset_process_options": (i32, []),
     "wl_sim_counter": (i32, [P, C.c_char_p, C.POINTER(C.c_long)]),
     "wl_prof_enable": (i32, [i32]),
     "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),

@@ -74,8 +74,11 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
       // whole level costs less than that to recompute on every rank
       // (WL_REPLICATE_PLANES overrides the 64: the tests use it to build, with 4 ranks, the small distributed slabs an 8-rank run has)
       static const int repl = [] { const char* e = getenv("WL_REPLICATE_PLANES"); const int v = e ? atoi(e) : 64; return v >= 8 ? v : 64; }();
-      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > repl;
-      if (cz && (nloc % 2 != 0)) { wl_set_error("z-slab: local plane count must stay even until the level is replicated (use nz = P*2^k)"); return WL_EINVAL; }
+      // … and a level whose local plane count is odd cannot be coarsened slab by slab (its plane pairs would straddle the ranks): the level that
+      // would come out odd AND is coarsened again in z is replicated right away — any nz with an even number of planes per rank works, not only P·2^k
+      const bool odd_next = divisible(gnz_c) && (nc % 2 != 0);
+      const bool keep = (!cz || (nloc % 2 == 0)) && nc >= 1 && (gnz_c - 2) > repl && !odd_next;
+      if (cz && (nloc % 2 != 0)) { wl_set_error("z-slab: the finest level needs an even number of planes per rank"); return WL_EINVAL; }
       if (keep) {
         cgr.gnz = gnz_c; cgr.k0 = f.k0; cgr.k1 = cgr.k0 + nc; cgr.nz = nc + 2 * cgr.k0;
         cgr.gk = (cz ? (f.gk + f.k0 + 1) / 2 : f.gk + f.k0) - cgr.k0;
@@ -194,6 +197,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
         const GridX g = sub(parts[i].a, parts[i].b);
         if (pro) {
           xdef[i] = use_xdefer && wl::gsrb_pair_B_ok(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, g, *parts[i].cl);
+          if (l == 0) last_xdefer = xdef[i] ? 1 : 0;
           WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, g, coarse.x_, w, *parts[i].cl, s, -(1 << 30), 1 << 30, &xdef[i]));
         } else WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, g, *parts[i].cl, s));
       }
@@ -222,6 +226,7 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
       p.pend = false;
       bool xdef = use_xdefer && wl::gsrb_pair_B_ok(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.x_, p.cl);   // `x += ω·x_c↓` handed from kernel A to kernel B
       const wl::XDefer xd{coarse.x, coarse.x_, w};
+      if (l == 0) last_xdefer = xdef ? 1 : 0;
       // z-slab: the tile pipeline recomputes the neighbour's planes it needs, so the exchanges are r (2 planes) before A and
       // ϵ_mid (3 planes) + r' (2 planes) before B — instead of one exchange per colour sweep
       if (p.dist && deep_halo && p.g.k0 >= 5 && p.g.k1 - p.g.k0 >= 5) {
@@ -359,7 +364,7 @@ int wl_mg::vcycle(int l, float w, hipStream_t s, bool defer) {                  
   fine.pend = true;
   return flush_pending(l, w, s);
 }
-int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s, bool have_residual) {   // solver! :108-128
+int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s, bool have_residual, const double* pre_r1, const float* pre_rinf) {   // solver! :108-128
   Level& p = lv[0];
   const double r1tol = (tol / 10.0) * (double)wl_ninside_global(p.g);                     // l1n_tol  src/Poisson.jl:194
   const double rinftol = tol;
@@ -370,7 +375,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
       WL_TRY(halo(p, p.x, 1, s));
       WL_TRY(wl::residual_part(p.r, p.x, p.z, p.L, p.D, p.iD, p.x_, ws, s));             // r and the local Σr -> res_d[0]
     }
-    WL_TRY(wl::combine_results(comm, ws, s));
+    if (!(jacobi0_done && pre_r1)) WL_TRY(wl::combine_results(comm, ws, s));   // (fused head: Σr, r₁, r∞ were combined and read by the caller)
     // mean shift + r₁ -> res_d[1], r∞ -> res_f[0] — unless the V-cycle's first operation is the z-marching Jacobi! on this level
     // (always run: nᵖ ≥ 1): that kernel applies the shift as it loads r and accumulates the norms, no pass over r at all
     shift_pending = !jacobi0_done && defer_shift && itmx >= 1 && !(comm && comm->size > 1) && !perdir && lv.size() > 1 && wl::jacobi_takes_shift(p.x_, p.cl);
@@ -382,6 +387,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
   bool have_r1 = false; float r1 = 0.f, rinf = 0.f;
   int np = 0;
   log_r1.clear(); log_rinf.clear(); log_w.clear();
+  if (jacobi0_done && pre_r1 && pre_rinf) { r1 = (float)*pre_r1; log_r1.push_back(*pre_r1); log_rinf.push_back((double)*pre_rinf); log_w.push_back(1.0); have_r1 = true; }
   while (np < itmx) {
     WL_TRY(vcycle(0, w, s, true));
     bool nd = false;
@@ -405,7 +411,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     if ((double)r1 < r1tol && (double)rinf < rinftol) break;
   }
   WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                        // :126
-  WL_TRY(halo(p, p.x, 1, s));                                                             // projection reads x[I-δz] across the slab face
+  WL_TRY(halo(p, p.x, 1, s, x_halo_depth));                                               // projection reads x[I-δz] across the slab face (the next solve's fused head two planes deep)
   n.push_back((int16_t)np);
   if (host_n) *host_n = np;
   if (host_r1) *host_r1 = (double)r1;

@@ -75,7 +75,9 @@ struct RcclComm : wl_comm {
   int sendrecv_body(ncclComm_t cm, const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) {
     // neighbours: lo = rank-1, hi = rank+1 (loopback: both are this rank — what it sends down comes back as its upper ghost planes and
     // vice versa, the z-periodic wrap; sends and receives to one peer match in issue order, hence lo-send / hi-recv first)
-    const int plo = loopback ? rank : (zperiodic ? (rank + size - 1) % size : rank - 1), phi = loopback ? rank : (zperiodic ? (rank + 1) % size : rank + 1);
+    const bool self = loopback || virt;
+    const int me = virt ? real_rank : rank;
+    const int plo = self ? me : (zperiodic ? (rank + size - 1) % size : rank - 1), phi = self ? me : (zperiodic ? (rank + 1) % size : rank + 1);
     if (slo) WL_NCCL(rccl().Send(slo, bytes, ncclChar, plo, cm, s));
     if (rhi) WL_NCCL(rccl().Recv(rhi, bytes, ncclChar, phi, cm, s));
     if (shi) WL_NCCL(rccl().Send(shi, bytes, ncclChar, phi, cm, s));
@@ -90,6 +92,12 @@ struct RcclComm : wl_comm {
     return rc ? rc : re;
   }
   int allgather(const void* send, void* recv, size_t bytes_each, hipStream_t s) override {
+    if (virt) {   // rehearsal: the one-rank all-gather lands in this rank's block; the other ranks' blocks are filled with copies of it (every pretended rank = this slab)
+      char* mine = (char*)recv + (size_t)rank * bytes_each;
+      WL_NCCL(rccl().AllGather(send, mine, bytes_each, ncclChar, comm, s));
+      for (int r = 0; r < size; r++) if (r != rank) WL_HIP(hipMemcpyAsync((char*)recv + (size_t)r * bytes_each, mine, bytes_each, hipMemcpyDeviceToDevice, s));
+      return 0;
+    }
     WL_NCCL(rccl().AllGather(send, recv, bytes_each, ncclChar, comm, s));
     return 0;
   }
@@ -196,6 +204,14 @@ int wl_comm_rccl_add_async(wl_comm* cc, const char uid[128]) {
   return 0;
 }
 int wl_comm_set_periodic(wl_comm* c, int on) { WL_CHECK(c, "null communicator"); c->zperiodic = on != 0; return 0; }
+int wl_comm_set_virtual(wl_comm* cc, int rank, int size) {
+  RcclComm* c = dynamic_cast<RcclComm*>(cc);
+  WL_CHECK(c && c->size == 1 && !c->virt, "the rehearsal mode needs a one-rank RCCL communicator");
+  WL_CHECK(size >= 2 && rank >= 0 && rank < size, "bad pretended rank/size");
+  if (c->gather) { (void)hipFree(c->gather); c->gather = nullptr; }      // (sized for the pretended number of ranks at the next use)
+  c->virt = true; c->real_rank = c->rank; c->real_size = c->size; c->rank = rank; c->size = size;
+  return 0;
+}
 int wl_comm_set_loopback(wl_comm* c, int on) { WL_CHECK(c && c->size == 1, "loopback is a one-rank test mode"); c->loopback = on != 0; return 0; }
 int wl_comm_halo_async(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* st) {
   WL_CHECK(g && g->D == 3, "halo exchange needs a 3-D slab grid");

@@ -6,6 +6,10 @@ struct wl_comm {
   int rank = 0, size = 1;
   bool zperiodic = false;   // the domain is periodic in z: rank 0's lower neighbour is rank size-1 and vice versa (halo exchanges wrap around)
   bool loopback = false;    // one-rank TEST mode: both neighbours are this rank (exercises the transport calls that size==1 skips)
+  // one-rank REHEARSAL mode (wl_comm_set_virtual): rank/size above are those of a pretended P-rank run — slab geometry, wall logic and the exchange
+  // pattern follow them — while the transport underneath has one rank: planes sent to a neighbour come back as this rank's own ghost planes.
+  // What one GPU can measure of a P-GPU step: the rank's compute, the number and size of its exchanges, the issue cost of the RCCL calls.
+  bool virt = false; int real_rank = 0, real_size = 1;
   void* gather = nullptr;   // device scratch for scalar all-gathers: size * 128 bytes
   virtual ~wl_comm();
   // lo neighbour = rank-1, hi neighbour = rank+1; pointers are NULL where there is no neighbour

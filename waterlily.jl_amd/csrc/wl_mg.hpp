@@ -33,6 +33,8 @@ struct wl_mg {
   bool deep_halo = true;     // z-slabs with >= 5 ghost planes: one r exchange (5 planes) per smooth! instead of r (2) + ϵ_mid (3) + r' (2)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
+  int x_halo_depth = 1;     // z-slabs: ghost planes of x refreshed at the end of solver! (the projection tail reads 1; the fused projection head of the NEXT solve reads 2)
+  int last_xdefer = -1;     // what the finest level's last smooth! with a pending prolongation decided: 1 = x += ω·x_c↓ deferred to kernel B, 0 = applied by kernel A (−1: none yet)
   bool use_xdefer = true;   // pair smoother: the V-cycle's `x += ω·x_c↓` is applied by kernel B together with its own increment (wl::XDefer)
   bool overlap_smooth = true;   // z-slabs: the one deep r exchange of a smooth! overlaps kernel A's interior planes (boundary slices after the wait)
   bool use_tail = true;     // levels of <= WL_TAIL_CELLS cells: the rest of the V-cycle in one launch (k_vcycle_tail)
@@ -53,5 +55,6 @@ struct wl_mg {
   int vcycle(int l, float w, hipStream_t s, bool defer = false);
   int flush_pending(int l, float w, hipStream_t s);
   // have_residual: r and the local Σr (ws.res_d[0]) were already produced by the caller's fused div+residual kernel
-  int solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s, bool have_residual = false);
+  // pre_r1 / pre_rinf: the norms of the initial residual are already on the host (the fused projection head's read-back, combined over ranks)
+  int solve(double tol, int itmx, int* host_n, double* host_r1, float* host_rinf, hipStream_t s, bool have_residual = false, const double* pre_r1 = nullptr, const float* pre_rinf = nullptr);
 };

@@ -98,10 +98,11 @@ __global__ void k_resjac_fin(const double* __restrict__ psum, const double* __re
 
 namespace wl {
 void resjac_enable(int on, long min_cells) { g_resjac_on = on; if (min_cells >= 0) g_resjac_min = min_cells; }
-// the fused head is worth it (and implemented) for: 3-D single-domain constant-coefficient finest levels of at least resjac_min cells
+// the fused head is worth it (and implemented) for: 3-D constant-coefficient finest levels (single domain or z-slab) of at least resjac_min cells
 bool resjac_ok(const GridX& g, const ConstL& cl) {
-  return g_resjac_on && cl.on && g.D == 3 && g.nz == g.gnz && g.gk == 0 && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 && g.nz >= 10 && g.cs < (1L << 30) &&
-         (long)(g.nx - 2) * (g.ny - 2) * (g.nz - 2) >= g_resjac_min;
+  // (z-slab: two ghost planes of x and u per side — the residual of the neighbour's boundary plane is recomputed; the size gate is on the GLOBAL level)
+  return g_resjac_on && cl.on && g.D == 3 && (g.nz == g.gnz ? g.gk == 0 : (g.k0 >= 2 && g.nz - g.k1 >= 2 && g.k1 - g.k0 >= 8)) && (g.nx & 1) == 0 && g.nx >= 66 && g.ny >= 34 &&
+         g.gnz >= 10 && g.cs < (1L << 30) && (long)(g.nx - 2) * (g.ny - 2) * (g.gnz - 2) >= g_resjac_min;
 }
 // z=∇·u; x_out = x·dt (+ω·ϵ on interior cells); r_out = residual after Jacobi!(ω=w); Σr -> res_d[0], L₁(r) -> res_d[slot_d], L∞(r) -> res_f[slot_f]
 // (the norms of the residual BEFORE Jacobi!, as solver! logs them).  x_out ≠ x, r_out's ghost cells are left untouched (zero).

@@ -431,6 +431,7 @@ struct wl_sim {
     WL_TRY(bdim_step(1.f, 0.5f, s));  // scale_u!(a,0.5) folded (post)
     return bc_u(s);
   }
+  int itmx = 32;             // solver!'s iteration cap (src/MultiLevelPoisson.jl:108); the multi-GPU rehearsal (tools/slab_rank_bench.py) lowers it to the 1 V-cycle the real run takes
   bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
   bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
   long n_resjac = 0, n_resjac_redo = 0;   // how often the fused head stood / had to be redone because the mean shift was due
@@ -448,13 +449,18 @@ struct wl_sim {
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
       wl_mg::Level& l0 = mg->lv[0];
       bool head_done = false;
-      if (use_resjac && !resjac_backoff && !d.exitBC && !store_f && !comm && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl)) {   // (exitBC: the convective exit leaves a net flux imbalance to the solver's tolerance — the shift is usually due)
+      double pre_r1 = 0.0; float pre_rinf = 0.f;
+      if (use_resjac && !resjac_backoff && !d.exitBC && !store_f && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl) &&
+          (!comm || (l0.dist && mg->x_halo_depth >= 2))) {   // (exitBC: the convective exit leaves a net flux imbalance to the solver's tolerance — the shift is usually due; z-slab: p's ghost planes are current two deep)
         // head + the V-cycle's first Jacobi!(fine) in one launch, assuming residual!'s mean shift is not due (wl_resjac.hip); Σr decides
         { ProfScope pr(WL_PROF_RESIDUAL, s);
           // p's and the spare's ghost cells are +0 unless someone wrote them from outside (checked once after a pointer to p was handed out): no shell pass then
+          if (comm) p_shell = 1;   // (a slab's ghost planes hold the neighbours' pressure: always scaled with the rest)
           if (p_shell < 0) p_shell = (wl::shell_nonzero(p, G, (int*)(mg->ws.res_f + 7), s) || wl::shell_nonzero(ps, G, (int*)(mg->ws.res_f + 7), s)) ? 1 : 0;
           WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s, p_shell != 0)); }
-        double sr; WL_TRY(wl::read_results(mg->ws, &sr, 1, nullptr, 0, s));
+        WL_TRY(wl::combine_results(comm, mg->ws, s));            // z-slabs: Σr, L₁ (sums) and L∞ (max) over the ranks — every rank takes the same branch below
+        double hd2[2]; WL_TRY(wl::read_results(mg->ws, hd2, 2, &pre_rinf, 1, s));
+        const double sr = hd2[0]; pre_r1 = hd2[1];
         const float sm = (float)sr / (float)(double)wl_ninside_global(mg->lv[0].g);
         if (std::fabs(sm) <= 2.f * 1.1920929e-7f && !resjac_force_redo) {                                       // src/Poisson.jl:96: no shift — the fused results stand
           std::swap(p, ps); l0.x = p;
@@ -473,7 +479,7 @@ struct wl_sim {
         } else WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s));
       }
       if (!head_done) { std::swap(p, ps); l0.x = p; }
-      WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s, true));
+      WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s, true, head_done ? &pre_r1 : nullptr, head_done ? &pre_rinf : nullptr));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
       const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
       const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
@@ -488,7 +494,7 @@ struct wl_sim {
       return bc_u(s);
     }
     WL_TRY(wl::div_scale(sigma, p, u, G, dtl, s));                                       // z=div(u); x.*=dt
-    WL_TRY(mg->solve(2e-3, 32, nullptr, nullptr, nullptr, s));
+    WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s));
     WL_TRY(wl::project(u, mu0, p, G, s));
     WL_TRY(wl::div_scalar(p, dtl, (size_t)G.cs, s));                                     // x./=dt
     return bc_u(s);
@@ -618,6 +624,9 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     if (slab || adopt->lv.empty() || adopt->lv[0].x != s->p || adopt->lv[0].L != s->mu0 || adopt->lv[0].z != s->sigma) {
       delete s; *out = nullptr; wl_set_error("wl_sim_create_on: the wl_mg handle was not built on this flow's p, mu0, sigma"); return WL_EINVAL;
     }
+    if (adopt->perdir != desc->perdir_mask) {   // the hierarchy's perBC! pattern is fixed at wl_mg_create: it has to be the flow's
+      delete s; *out = nullptr; wl_set_error("wl_sim_create_on: the wl_mg handle was created with a different perdir mask than desc->perdir_mask"); return WL_EINVAL;
+    }
     s->mg = adopt; s->own_mg = false;
   } else {
     s->mg = new wl_mg();
@@ -625,6 +634,7 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
     if (rc != 0) { delete s; *out = nullptr; return rc; }
   }
   s->mg->store_eps = false;   // p.ϵ is pure scratch on the time-step path
+  if (slab && s->G.k0 >= 2 && s->G.nz - s->G.k1 >= 2) s->mg->x_halo_depth = 2;   // z-slab: the fused projection head recomputes the residual of the neighbour's boundary plane (x two planes deep)
   *out = s; return 0;
 }
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) { return sim_create_common(out, desc, nullptr); }
@@ -679,6 +689,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "jacobi_march") { wl::jacobi_march_enable(value); return 0; }
   if (n == "convm") { wl::conv_march_enable(value); return 0; }
   if (n == "deep_halo") { s->mg->deep_halo = value != 0; return 0; }
+  if (n == "x_halo") { if (value < 1 || value > s->G.k0) { wl_set_error("x_halo: 1 .. ghost depth of the slab"); return WL_EINVAL; } s->mg->x_halo_depth = value; return 0; }   // 1: the fused head stays off on z-slabs
   if (n == "bcfold") { s->use_bcfold = value; return 0; }   // bit 0: projection tails, bit 1: tiled conv_diff!+BDIM!
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
@@ -686,17 +697,25 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
+  if (n == "itmx") { if (value < 1) { wl_set_error("itmx must be >= 1"); return WL_EINVAL; } s->itmx = value; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
 int wl_sim_update(wl_sim* s, void* st) { s->resjac_backoff = false; s->resjac_redo_run = 0; WL_TRY(s->refresh_body_mask(wl_stream(st))); return s->mg->update(wl_stream(st)); }
 
 long wl_launch_count(void) { return g_wl_launches; }
+// the size gates and kernel-family switches that wl_sim_set_option / wl_mg_set_fused keep PROCESS-wide (they select code, not results): back to the defaults
+int wl_reset_process_options(void) {
+  wl::resjac_enable(1, 6L << 20); wl::conv_tile_min(2048); wl::conv_tile_enable(1, 0); wl::tail_lds_enable(1); wl::conv_body_tile_enable(1);
+  wl::gsrb_pair_enable(1); wl::jacobi_march_enable(1); wl::conv_march_enable(0);
+  return 0;
+}
 int wl_sim_counter(wl_sim* s, const char* name, long* out) {
   WL_CHECK(s && name && out, "bad argument");
   const std::string n(name);
   if (n == "resjac") { *out = s->n_resjac; return 0; }
   if (n == "resjac_redo") { *out = s->n_resjac_redo; return 0; }
   if (n == "resjac_backoff") { *out = s->resjac_backoff ? 1 : 0; return 0; }
+  if (n == "xdefer") { *out = s->mg->last_xdefer; return 0; }
   wl_set_error("unknown counter " + n); return WL_EINVAL;
 }
 int wl_sim_set_forcing(wl_sim* s, const float* U1, const float* a0, const float* a1) {

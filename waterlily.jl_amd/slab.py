@@ -314,7 +314,10 @@ def bench_main(args, world, rank, local_rank, read_prof=None, build_roofline=Non
             mg = lib().wl_sim_pois(sim._h)
             g = sim.grid
             ncell_local = float(N) * float(N) * float(g.k1 - g.k0)
-            roof = build_roofline(prof, ncell_local, bool(lib().wl_mg_level_is_const(mg, 0)), int(lib().wl_mg_smoother_kind(mg, 0)), N, use_traffic=False)
+            import ctypes as _C
+            xd = _C.c_long(-1)
+            check(lib().wl_sim_counter(sim._h, b"xdefer", _C.byref(xd)))
+            roof = build_roofline(prof, ncell_local, bool(lib().wl_mg_level_is_const(mg, 0)), int(lib().wl_mg_smoother_kind(mg, 0)), N, use_traffic=False, xdefer=int(xd.value))
             roof["scope"] = f"rank 0 of {world}: its {g.k1 - g.k0} planes of the finest level"
         except Exception as e:   # noqa: BLE001 — the throughput line must not depend on the optional roofline block
             roof = {"error": repr(e)}
