@@ -1,0 +1,56 @@
+// Does the PLACEMENT of an allocation decide what a z-marching kernel gets out of HBM?  (round 3: the same binary measured 3.7 or 4.7 TB/s for
+// kernel A's memory mix from one process to the next, identical within a process.)  One process, several rounds: allocate the five 543-MB arrays
+// (one hipMalloc), time the A-mix and P-mix z-march (64x32-cell tiles, 1024 threads) and an element-wise pass, free; between rounds a growing
+// "spoiler" allocation is kept so that the next round lands elsewhere.
+// build: hipcc -O3 --offload-arch=gfx950 -o place_probe place_probe.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); exit(1); } } while (0)
+static const int N = 512, NG = 514;
+__global__ void __launch_bounds__(1024) k_tileA(const float* __restrict__ r, float* __restrict__ ro, float* __restrict__ eo, int zc, float w) {
+  const size_t psz = (size_t)NG * NG;
+  const int ntx = N / 64, nty = N / 32, ntiles = ntx * nty;
+  const unsigned h = blockIdx.x, q = h & 7u, s = h >> 3, per = (unsigned)((ntiles + 7) >> 3);
+  const int ch = (int)(s / per), tl = (int)(q * per + (s - (unsigned)ch * per));
+  if (tl >= ntiles) return;
+  const int tx = tl % ntx, ty = tl / ntx;
+  const int slot = threadIdx.x, row = slot / 32, col = (slot % 32) * 2;
+  const size_t o = (size_t)(1 + ty * 32 + row) * NG + (size_t)(2 + tx * 64 + col);
+  const int k0 = 1 + ch * zc, k1 = min(k0 + zc, 1 + N);
+  float2 a = *(const float2*)(r + o + (size_t)k0 * psz);
+  for (int k = k0; k < k1; k++) {
+    const float2 n = *(const float2*)(r + o + (size_t)min(k + 1, k1 - 1) * psz);
+    *(float2*)(ro + o + (size_t)k * psz) = a; a.x *= w; a.y *= w; *(float2*)(eo + o + (size_t)k * psz) = a;
+    a = n;
+  }
+}
+__global__ void __launch_bounds__(256) k_elemA(const float2* __restrict__ r, float2* __restrict__ ro, float2* __restrict__ eo, size_t n, float w) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { float2 b = r[i]; ro[i] = b; b.x *= w; b.y *= w; eo[i] = b; }
+}
+int main(int argc, char** argv) {
+  const size_t ntot = (size_t)NG * NG * NG, bytes = ntot * 4;
+  const size_t sp = ((bytes + (2u << 20) - 1) >> 21) << 21;
+  hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
+  std::vector<void*> spoil;
+  const int rounds = argc > 1 ? atoi(argv[1]) : 8;
+  for (int rd = 0; rd < rounds; rd++) {
+    char* base; CK(hipMalloc(&base, 3 * sp));
+    float* r = (float*)base; float* ro = (float*)(base + sp); float* eo = (float*)(base + 2 * sp);
+    CK(hipMemset(base, 1, 3 * sp));
+    float ms[2];
+    for (int which = 0; which < 2; which++) {
+      auto launch = [&] { if (which == 0) k_tileA<<<8 * 16 * 10, 1024>>>(r, ro, eo, 52, 0.5f); else k_elemA<<<262144, 256>>>((const float2*)r, (float2*)ro, (float2*)eo, ntot / 2, 0.5f); };
+      launch(); launch();
+      CK(hipEventRecord(t0)); for (int q = 0; q < 5; q++) launch(); CK(hipEventRecord(t1)); CK(hipEventSynchronize(t1));
+      CK(hipEventElapsedTime(&ms[which], t0, t1)); ms[which] /= 5;
+    }
+    const double cells = (double)N * N * N;
+    printf("round %d  base %p  z-march A-mix %6.3f ms = %5.2f TB/s   element-wise %6.3f ms = %5.2f TB/s\n", rd, (void*)base, ms[0], 12.0 * cells / ms[0] / 1e9, ms[1], 12.0 * cells / ms[1] / 1e9);
+    fflush(stdout);
+    if (argc > 2) { spoil.push_back(base); }      // argv[2]: "hold" — keep every block (the next one is new memory)
+    else { CK(hipFree(base)); void* s; CK(hipMalloc(&s, (size_t)(97 + 61 * rd) << 20)); spoil.push_back(s); }      // the next round lands elsewhere
+  }
+  return 0;
+}

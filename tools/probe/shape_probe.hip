@@ -62,7 +62,7 @@ template <int MIX, int NV, int NT> __device__ __forceinline__ void store_plane(R
 
 // tile W x H cells, T threads, NV = W*H/(2T) float2 per thread and plane; P planes of loads in flight (1 or 2)
 template <int MIX, int W, int H, int T, int P, int NT>
-__global__ void __launch_bounds__(T) k_tile(Arr A, int nx, int ny, int nz, int pitch, size_t psz, int zc, float w, float* sink) {
+__global__ void __launch_bounds__(T) k_tile(Arr A, int nx, int ny, int nz, int pitch, size_t psz, int zc, float w, float* sink, int oi = 2, int oj = 1, int ok = 1) {
   constexpr int NV = W * H / (2 * T);
   static_assert(NV >= 1, "tile too small");
   const int ntx = (nx + W - 1) / W, nty = (ny + H - 1) / H, ntiles = ntx * nty;
@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(T) k_tile(Arr A, int nx, int ny, int nz, int p
     int i = tx * W + col, j = ty * H + row;
     if (i > nx - 2) i = nx - 2;
     if (j > ny - 1) j = ny - 1;                     // clamp (ragged edge tiles re-do the last row: harmless for a probe)
-    o[v] = (size_t)(1 + j) * pitch + (size_t)(2 + i);   // interior cells start at column 2 (8-byte aligned pairs), row 1
+    o[v] = (size_t)(oj + j) * pitch + (size_t)(oi + i);   // interior cells start at column 2 (8-byte aligned pairs), row 1
   }
-  const int k0 = 1 + ch * zc, k1 = min(k0 + zc, 1 + nz);
+  const int k0 = ok + ch * zc, k1 = min(k0 + zc, ok + nz);
   float2 acc = {0.f, 0.f};
   Regs<MIX, NV, NT> r0, r1;
   load_plane<MIX, NV, NT>(r0, A, o, (size_t)k0 * psz);
@@ -189,8 +189,10 @@ __global__ void __launch_bounds__(256) k_scatter(Arr A, unsigned nseg_log2, unsi
   if (MIX == MIX_R && accs == 1.2345f) sink[0] = accs;
 }
 
-static const int N = 512, NG = 514;
-static const size_t PSZ = (size_t)NG * NG, NTOT = PSZ * NG;
+static const int N = 512;
+static int NG = 514;            // row pitch = planes' side with ghosts (argv[2]: 512 = no ghost cells, power-of-two strides; 516/520/528: padded rows)
+static size_t PSZ, NTOT;
+static int OI = 2, OJ = 1, OK = 1;   // first interior cell
 static hipEvent_t t0, t1;
 static const double mixbytes[5] = {20.0, 12.0, 8.0, 12.0, 32.0};
 static const char* mixname[5] = {"B(3R+2W)", "A(1R+2W)", "C(copy)", "R(3R)", "P(4R+4W)"};
@@ -218,7 +220,7 @@ template <int MIX, int W, int H, int T, int P, int NT> static void run_tile(int 
   const int ntx = (N + W - 1) / W, nty = (N + H - 1) / H, per = (ntx * nty + 7) >> 3;
   const int zc = (N + chunks - 1) / chunks, nch = (N + zc - 1) / zc;
   char nm[96]; snprintf(nm, 96, "tile %3dx%-2d T%-4d P%d %s ch%-2d (%d wg)", W, H, T, P, NT ? "nt" : "  ", nch, 8 * per * nch);
-  timeit(nm, MIX, [&] { k_tile<MIX, W, H, T, P, NT><<<8 * per * nch, T>>>(A, N, N, N, NG, PSZ, zc, 0.5f, sink); });
+  timeit(nm, MIX, [&] { k_tile<MIX, W, H, T, P, NT><<<8 * per * nch, T>>>(A, N, N, N, NG, PSZ, zc, 0.5f, sink, OI, OJ, OK); });
 }
 template <int MIX, int S, int T, int P, int NT> static void run_span(int chunks) {
   const int nsp = (int)((PSZ + S - 1) / S), per = (nsp + 7) >> 3;
@@ -305,19 +307,42 @@ template <int MIX> static void run_locality() {
 }
 
 int main(int argc, char** argv) {
+  if (argc > 2) NG = atoi(argv[2]);
+  if (NG == N) { OI = 0; OJ = 0; OK = 0; }
+  PSZ = (size_t)NG * NG; NTOT = PSZ * NG;
   float *e, *r, *x, *ro, *eo;
   const size_t bytes = NTOT * 4 + 4096;
-  CK(hipMalloc(&e, bytes)); CK(hipMalloc(&r, bytes)); CK(hipMalloc(&x, bytes)); CK(hipMalloc(&ro, bytes)); CK(hipMalloc(&eo, bytes)); CK(hipMalloc(&sink, 64));
+  // argv[3] (bytes, optional): all five arrays in ONE allocation, array q at q·(round_up(bytes, 2 MiB) + delta) — relative placement under control
+  const long delta = argc > 3 ? atol(argv[3]) : -1;
+  if (delta >= 0) {
+    const size_t sp = ((bytes + (2u << 20) - 1) >> 21 << 21) + (size_t)delta;
+    char* base; CK(hipMalloc(&base, 5 * sp + (4u << 20)));
+    e = (float*)base; r = (float*)(base + sp); x = (float*)(base + 2 * sp); ro = (float*)(base + 3 * sp); eo = (float*)(base + 4 * sp);
+    printf("# one allocation, spacing %zu + %ld bytes\n", sp - (size_t)delta, delta);
+  } else { CK(hipMalloc(&e, bytes)); CK(hipMalloc(&r, bytes)); CK(hipMalloc(&x, bytes)); CK(hipMalloc(&ro, bytes)); CK(hipMalloc(&eo, bytes)); }
+  CK(hipMalloc(&sink, 64));
   // random-ish data (DVFS: zero-filled inputs clock higher than real data)
   std::vector<float> hbuf(NTOT);
   unsigned s = 12345u; for (size_t i = 0; i < NTOT; i++) { s = s * 1664525u + 1013904223u; hbuf[i] = (float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f; }
   for (float* p : {e, r, x, ro, eo}) CK(hipMemcpy(p, hbuf.data(), NTOT * 4, hipMemcpyHostToDevice));
   A = Arr{e, r, x, ro, eo};
   CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
-  printf("# arrays %dx%dx%d floats (512^3 cells with ghosts), bytes per cell: B 20, A 12, C 8, R 12; TB/s = bytes/cell x 512^3 / avg time\n", NG, NG, NG);
+  printf("# arrays %dx%dx%d floats (512^3 cells; pitch = side incl. ghost/pad cells), bytes per cell: B 20, A 12, C 8, R 12; TB/s = bytes/cell x 512^3 / avg time\n", NG, NG, NG);
   printf("# pointers e %p r %p x %p ro %p eo %p\n", (void*)e, (void*)r, (void*)x, (void*)ro, (void*)eo);
   const char* only = argc > 1 ? argv[1] : "BACR";
   for (const char* p = only; *p; p++) {
+    if (*p == 'T') {   // the core comparisons, three rounds interleaved (clock states and placement luck show as spread)
+      for (int rep = 0; rep < 3; rep++) {
+        timeit("elem 4B/lane grid 262144", MIX_B, [&] { k_elem<MIX_B, float><<<262144, 256>>>(A, NTOT, 0.5f, sink); });
+        run_tile<MIX_B, 64, 32, 1024, 1, 0>(10); run_tile<MIX_B, 64, 32, 1024, 1, 0>(32); run_tile<MIX_B, 256, 4, 256, 1, 0>(16);
+        timeit("elem 8B/lane grid 262144", MIX_A, [&] { k_elem<MIX_A, float2><<<262144, 256>>>(A, NTOT / 2, 0.5f, sink); });
+        run_tile<MIX_A, 64, 32, 1024, 1, 0>(10); run_tile<MIX_A, 64, 32, 1024, 1, 0>(32);
+      }
+    }
+    if (*p == 'S') {   // stride study: the reference tile shapes only (run with argv[2] = 512, 514, 516, 520, 528, 544)
+      run_tile<MIX_B, 64, 32, 1024, 1, 0>(10); run_tile<MIX_B, 64, 32, 1024, 1, 0>(32); run_tile<MIX_B, 256, 4, 256, 1, 0>(16);
+      run_tile<MIX_A, 64, 32, 1024, 1, 0>(10); run_tile<MIX_A, 64, 32, 1024, 1, 0>(32); run_tile<MIX_P, 64, 32, 1024, 1, 0>(10);
+    }
     if (*p == 'L') { run_locality<MIX_B>(); run_locality<MIX_R>(); run_locality<MIX_C>(); }
     if (*p == 'P') {
       run_elems<MIX_P>();
