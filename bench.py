@@ -267,6 +267,10 @@ def main():
                                cpu_baseline=None if args.no_cpu_baseline else (lambda: cpu_baseline(budget_s=args.cpu_budget)))
 
     sim = w.FusedSimulation((N, N, N), (0, 0, 0), N, U=1, nu=N / 1600.0, ic="tgv")
+    import ctypes as C
+    sc = (C.c_double * 8)()
+    nsc = lib.wl_placement_scores(sc, 8)      # wl_sim_create's placement trials (large grids): ms of a timed mom_project! pair per candidate allocation; the fastest was kept
+    placement = [round(float(sc[i]), 3) for i in range(min(nsc, 8))]
     for key, val in os.environ.items():      # A/B switches for experiments: WL_OPT_<option of wl_sim_set_option>=0/1 (defaults: fast paths on)
         if key.startswith("WL_OPT_"):
             sim.set_option(key[7:], int(val))
@@ -276,7 +280,6 @@ def main():
     n_warm = len(sim.pois_n)
     all_phases = args.phases or (any(k.startswith("WL_OPT_") for k in os.environ) and not args.no_phases)
     check(lib.wl_prof_enable(1 if all_phases else 2))
-    import ctypes as C
     def counter(name):
         v = C.c_long()
         check(lib.wl_sim_counter(sim._h, name.encode(), C.byref(v)))
@@ -302,7 +305,7 @@ def main():
                    "size": N, "mean_pois_n": float(sum(pn)) / max(1, len(pn)), "dt_last": float(sim.dt[-1]),
                    "constant_coefficient_levels": sim.const_levels(), "smoother_kinds": sim.smoother_kinds(),
                    # kernel launches per mom_step! in the timed region; solves whose fused projection head stood / had to be redone (residual!'s mean shift due)
-                   "launches_per_step": launches_per_step, "resjac": counter("resjac") - rj0, "resjac_redo": counter("resjac_redo") - rd0},
+                   "placement_trial_ms": placement, "launches_per_step": launches_per_step, "resjac": counter("resjac") - rj0, "resjac_redo": counter("resjac_redo") - rd0},
         "roofline": roof,
         "phases_ms_per_step": {k: (v["total_ms"] / args.steps) for k, v in prof.items() if v["launches"]},
     }

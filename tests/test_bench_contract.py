@@ -53,16 +53,15 @@ def test_roofline_frac_is_own_bytes_not_operation_bytes(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     ncell = 512.0**3
-    monkeypatch.setenv("WL_OPT_xdefer", "0")        # round-1 kernel pair: A updates x itself
-    roof = bench.build_roofline(_fake_prof(0.86, 0.75), ncell, True, 2, 512, use_traffic=False)
+    # round-1 kernel pair: A updates x itself (the library reports which kernel applied the V-cycle's x increment: wl_sim_counter "xdefer")
+    roof = bench.build_roofline(_fake_prof(0.86, 0.75), ncell, True, 2, 512, use_traffic=False, xdefer=0)
     own = (20.5 + 20.0) * ncell / 1.61e-3 / 1e9
     assert roof["bytes_per_cell"] == 40.5 and abs(roof["achieved"] - own) < 1e-6 * own
     assert abs(roof["frac"] - own / 8000.0) < 1e-9 and 0.40 < roof["frac"] < 0.44          # 0.42, not 0.80
     assert roof["op_equivalent"]["bytes_per_cell"] == 76.5 and 0.78 < roof["op_equivalent"]["frac"] < 0.82
     assert roof["traffic"] is None and roof["traffic_frac"] is None
     # default pair kernels: `x += ω·x_c↓` is applied by kernel B — the pair owns 8 B/cell less, and frac is quoted on what it owns
-    monkeypatch.delenv("WL_OPT_xdefer")
-    roof = bench.build_roofline(_fake_prof(0.49, 0.70), ncell, True, 2, 512, use_traffic=False)
+    roof = bench.build_roofline(_fake_prof(0.49, 0.70), ncell, True, 2, 512, use_traffic=False, xdefer=1)
     assert roof["x_increment_deferred_to_B"] and roof["bytes_per_cell"] == 33.0
     assert roof["kernels"]["A"]["bytes_per_cell"] == 12.5 and roof["kernels"]["B"]["bytes_per_cell"] == 20.5
     assert abs(roof["frac"] - 33.0 * ncell / 1.19e-3 / 1e9 / 8000.0) < 1e-9

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <time.h>
 #define CK(x) do { hipError_t err_ = (x); if (err_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(err_), __LINE__); exit(1); } } while (0)
 static const int N = 512, NG = 514;
 __global__ void __launch_bounds__(1024) k_tileA(const float* __restrict__ r, float* __restrict__ ro, float* __restrict__ eo, int zc, float w) {
@@ -35,6 +36,19 @@ int main(int argc, char** argv) {
   hipEvent_t t0, t1; CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
   std::vector<void*> spoil;
   const int rounds = argc > 1 ? atoi(argv[1]) : 8;
+  if (argc > 2 && argv[2][0] == 't') {   // "time": ONE allocation timed `rounds` times, 100 ms apart — placement fixed, only time passes
+    char* base; CK(hipMalloc(&base, 3 * sp)); CK(hipMemset(base, 1, 3 * sp));
+    float* r = (float*)base; float* ro = (float*)(base + sp); float* eo = (float*)(base + 2 * sp);
+    for (int rd = 0; rd < rounds; rd++) {
+      float ms;
+      k_tileA<<<8 * 16 * 10, 1024>>>(r, ro, eo, 52, 0.5f);
+      CK(hipEventRecord(t0)); for (int q = 0; q < 5; q++) k_tileA<<<8 * 16 * 10, 1024>>>(r, ro, eo, 52, 0.5f); CK(hipEventRecord(t1)); CK(hipEventSynchronize(t1));
+      CK(hipEventElapsedTime(&ms, t0, t1)); ms /= 5;
+      printf("t=%4d ms  same allocation %p  z-march A-mix %6.3f ms = %5.2f TB/s\n", rd * 100, (void*)base, ms, 12.0 * 512.0 * 512 * 512 / ms / 1e9); fflush(stdout);
+      struct timespec ts = {0, 100000000}; nanosleep(&ts, nullptr);
+    }
+    return 0;
+  }
   for (int rd = 0; rd < rounds; rd++) {
     char* base; CK(hipMalloc(&base, 3 * sp));
     float* r = (float*)base; float* ro = (float*)(base + sp); float* eo = (float*)(base + 2 * sp);

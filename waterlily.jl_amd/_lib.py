@@ -148,6 +148,7 @@ SIGNATURES = {
     "wl_sim_create_slab": (i32, [C.POINTER(P), C.POINTER(wl_sim_desc), P]),
     "wl_launch_count": (C.c_long, []),
     "wl_reset_process_options": (i32, []),
+    "wl_placement_scores": (i32, [C.POINTER(C.c_double), i32]),
     "wl_sim_counter": (i32, [P, C.c_char_p, C.POINTER(C.c_long)]),
     "wl_prof_enable": (i32, [i32]),
     "wl_prof_read": (i32, [i32, C.POINTER(i32), C.POINTER(f64)]),

@@ -637,7 +637,61 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
   if (slab && s->G.k0 >= 2 && s->G.nz - s->G.k1 >= 2) s->mg->x_halo_depth = 2;   // z-slab: the fused projection head recomputes the residual of the neighbour's boundary plane (x two planes deep)
   *out = s; return 0;
 }
-int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) { return sim_create_common(out, desc, nullptr); }
+// Placement trials.  Where the driver puts a multi-GB allocation decides what the z-marching kernels get out of HBM: the same binary ran the
+// finest-level smoother kernels 7–12 % and the fused projection head 9 % slower on one allocation than on the next (one process, simulations created
+// one after the other: profiles/r03_placement_trial.txt; a plain z-marching copy: 3.6 vs 4.7 TB/s, profiles/r03_place_probe2.txt) — element-wise
+// kernels do not care.  A handle that owns all its arrays therefore creates up to `trials` candidates (each in new memory: the others are held meanwhile),
+// times mom_project! once on each (zero fields: every kernel of the projection runs, nothing changes) and keeps the fastest.  Results are placement-
+// independent; only large grids take part (small ones live in the caches).  WL_PLACEMENT_TRIALS=1 switches it off.
+static double placement_score(wl_sim* s) {
+  hipStream_t q = 0;
+  const size_t n0 = s->mg->n.size();
+  if (s->project(1.f, q) != 0) return 1e30;            // warm-up (first-launch costs)
+  if (hipStreamSynchronize(q) != hipSuccess) return 1e30;
+  hipEvent_t a, b; if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 1e30;
+  float ms = 1e30f; int rc = 0;
+  for (int rep = 0; rep < 2 && rc == 0; rep++) {        // the faster of two timed pairs (each holds host read-backs of the solver)
+    (void)hipEventRecord(a, q);
+    rc = s->project(1.f, q); if (rc == 0) rc = s->project(0.5f, q, true);
+    (void)hipEventRecord(b, q); (void)hipEventSynchronize(b);
+    float t = 1e30f; (void)hipEventElapsedTime(&t, a, b);
+    if (t < ms) ms = t;
+  }
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  // back to the state of a fresh handle: pois.n, counters, Δt untouched by mom_project!; u, p are still zero (BC! wrote the boundary values the
+  // initial condition / init_flow will write again)
+  s->mg->n.resize(n0); s->n_resjac = 0; s->n_resjac_redo = 0; s->resjac_redo_run = 0; s->resjac_backoff = false; s->cfl_done = false;
+  s->mg->log_r1.clear(); s->mg->log_rinf.clear(); s->mg->log_w.clear();
+  return rc == 0 ? (double)ms : 1e30;
+}
+static double g_last_placement[8]; static int g_last_placement_n = 0;
+int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) {
+  WL_CHECK(out && desc, "null pointer");
+  static const int trials_env = [] { const char* e = getenv("WL_PLACEMENT_TRIALS"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  const bool owned = !desc->u && !desc->u0 && !desc->f && !desc->p && !desc->sigma && !desc->V && !desc->mu0 && !desc->mu1 && !desc->us;
+  const long cells = (long)desc->dims[0] * desc->dims[1] * (desc->D == 3 ? desc->dims[2] : 1);
+  int trials = (owned && desc->D == 3 && cells >= (48L << 20)) ? trials_env : 1;      // (≥ 48 Mi cells: the arrays are far larger than the Infinity Cache)
+  if (trials > 1) {   // all candidates are alive until the choice is made: never take more than half of the free memory for them (≈160 B per cell and candidate)
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess) { const long fit = (long)(fr / 2 / ((size_t)cells * 160 + 1)); if (fit < trials) trials = fit < 1 ? 1 : (int)fit; }
+  }
+  g_last_placement_n = 0;
+  if (trials == 1) return sim_create_common(out, desc, nullptr);
+  wl_sim* cand[8] = {nullptr}; double score[8]; int best = -1;
+  for (int i = 0; i < trials; i++) {
+    const int rc = sim_create_common(&cand[i], desc, nullptr);
+    if (rc != 0) { cand[i] = nullptr; if (best < 0 && i == trials - 1) return rc; break; }      // (out of memory for another candidate: go with what exists)
+    score[i] = placement_score(cand[i]);
+    g_last_placement[g_last_placement_n++] = score[i];
+    if (best < 0 || score[i] < score[best]) best = i;
+  }
+  if (best < 0) return WL_EINVAL;
+  for (int i = 0; i < trials; i++) if (cand[i] && i != best) delete cand[i];
+  *out = cand[best];
+  return 0;
+}
+// scores (ms of the timed mom_project! pair) of the candidates of the last wl_sim_create: measurement interface
+int wl_placement_scores(double* out, int cap) { int k = 0; for (; k < g_last_placement_n && k < cap; k++) out[k] = g_last_placement[k]; return g_last_placement_n; }
 int wl_sim_create_on(wl_sim** out, const wl_sim_desc* desc, wl_mg* mg) { WL_CHECK(mg, "null wl_mg"); return sim_create_common(out, desc, nullptr, mg); }
 int wl_sim_create_slab(wl_sim** out, const wl_sim_desc* desc, wl_comm* comm) { return sim_create_common(out, desc, comm); }
 int wl_sim_destroy(wl_sim* s) { delete s; return 0; }
