@@ -233,6 +233,100 @@ __global__ void k_project_cfl(GridX g, float* __restrict__ uout, const float* __
 #endif
 }
 __global__ void k_enc_init(int* __restrict__ p) { p[threadIdx.x] = (int)0x80000000; }
+// ---- the projection tails with TWO x-adjacent cells per thread, one plane per block, linear block order (3-D, constant coefficients, even nx) -----------
+// Same statements per cell as k_project_unscale / k_project_cfl.  Why a second form: in linear order (the order HBM serves best, wl_tile_lin) the one-cell
+// kernels are bound by L1 requests — 7 (unscale) / 13 (cfl) dword loads per cell; as float2 pairs the same cells need about half of them.
+// Block h: chunk (h mod nb8) of 512 consecutive floats of plane (h div nb8); a pair never straddles a row (nx even, pairs start at even columns).
+__device__ __forceinline__ float2 pl_ld2(const float* __restrict__ p, long o) { return *reinterpret_cast<const float2*>(p + o); }
+__device__ __forceinline__ void pl_st2(float* __restrict__ p, long o, float2 v) { *reinterpret_cast<float2*>(p + o) = v; }
+__device__ __forceinline__ bool pl_pair(const GridX& g, long& m, int& k, int p0) {
+  const long np2 = (g.sz / 2 + WL_BLOCK - 1) / WL_BLOCK;          // 256-pair chunks per plane
+  const unsigned nb8 = (unsigned)(((np2 + 7) >> 3) << 3);
+  const unsigned h = blockIdx.x;
+  const unsigned p = h / nb8;
+  k = p0 + (int)p;
+  m = 2 * ((long)(h - p * nb8) * WL_BLOCK + threadIdx.x);
+  return m < g.sz;
+}
+static inline unsigned pl_grid(const GridX& g, int nplanes) { const long np2 = (g.sz / 2 + WL_BLOCK - 1) / WL_BLOCK; return (unsigned)((((np2 + 7) >> 3) << 3) * nplanes); }
+__global__ void __launch_bounds__(WL_BLOCK) k_project_unscale2(GridX g, float* __restrict__ u, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl,
+                                                                  int p0, int p1, BcFold bc) {
+  long m; int k;
+  if (!pl_pair(g, m, k, p0) || k >= p1) return;
+  const int j = (int)(m / g.nx), i0 = (int)(m - (long)j * g.nx);
+  const long o = m + (long)k * g.sz;
+  const float2 xc = pl_ld2(x, o);
+  pl_st2(pout, o, make_float2(xc.x / dt, xc.y / dt));
+  if (!(j >= 1 && j <= g.ny - 2 && k >= g.k0 && k < g.k1)) return;
+  const bool in0 = i0 >= 1, in1 = i0 + 1 <= g.nx - 2;                 // (i0 is even: i0 <= nx-2 always; cell 0 is a ghost only at i0 == 0)
+  const float xl = in0 ? x[o - 1] : 0.f;
+  const float2 xy = pl_ld2(x, o - g.sy), xz = pl_ld2(x, o - g.sz);
+  const float2 u0 = pl_ld2(u, o), u1 = pl_ld2(u, g.cs + o), u2 = pl_ld2(u, 2 * g.cs + o);
+  const float lx0 = wl::wl_cl_coef(i0 + 1, g.nx, cl.c[0]), lx1 = wl::wl_cl_coef(i0 + 2, g.nx, cl.c[0]);
+  const float ly = wl::wl_cl_coef(j + 1, g.ny, cl.c[1]), lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]);
+  const float va[3] = {u0.x - lx0 * (xc.x - xl), u1.x - ly * (xc.x - xy.x), u2.x - lz * (xc.x - xz.x)};
+  const float vb[3] = {u0.y - lx1 * (xc.y - xc.x), u1.y - ly * (xc.y - xy.y), u2.y - lz * (xc.y - xz.y)};
+  if (bc.on && !(wl_bc_fold_plain(g, i0, j, k) && wl_bc_fold_plain(g, i0 + 1, j, k))) {
+    if (in0) { if (wl_bc_fold_plain(g, i0, j, k)) { u[o] = va[0]; u[g.cs + o] = va[1]; u[2 * g.cs + o] = va[2]; } else wl_bc_fold_store(u, g, i0, j, k, va, bc.U); }
+    if (in1) { if (wl_bc_fold_plain(g, i0 + 1, j, k)) { u[o + 1] = vb[0]; u[g.cs + o + 1] = vb[1]; u[2 * g.cs + o + 1] = vb[2]; } else wl_bc_fold_store(u, g, i0 + 1, j, k, vb, bc.U); }
+    return;
+  }
+  if (in0 && in1) { pl_st2(u, o, make_float2(va[0], vb[0])); pl_st2(u, g.cs + o, make_float2(va[1], vb[1])); pl_st2(u, 2 * g.cs + o, make_float2(va[2], vb[2])); }
+  else if (in0) { u[o] = va[0]; u[g.cs + o] = va[1]; u[2 * g.cs + o] = va[2]; }
+  else if (in1) { u[o + 1] = vb[0]; u[g.cs + o + 1] = vb[1]; u[2 * g.cs + o + 1] = vb[2]; }
+}
+__global__ void __launch_bounds__(WL_BLOCK) k_project_cfl2(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ x, float* __restrict__ pout,
+                                                              float* __restrict__ sigma, float dt, wl::ConstL cl, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1,
+                                                              int store_sigma, BcFold bc) {
+  long m; int k;
+  float mx = -INFINITY;
+  if (pl_pair(g, m, k, p0) && k < p1) {
+    const int j = (int)(m / g.nx), i0 = (int)(m - (long)j * g.nx);
+    const long o = m + (long)k * g.sz;
+    const float2 xc = pl_ld2(x, o);
+    pl_st2(pout, o, make_float2(xc.x / dt, xc.y / dt));
+    const bool row = j >= 1 && j <= g.ny - 2 && k >= g.k0 && k < g.k1;
+    const bool in0 = row && i0 >= 1, in1 = row && i0 + 1 <= g.nx - 2;
+    const bool want = k >= kfirst && k < klast;
+    float sg0 = 0.f, sg1 = 0.f;
+    if (in0 || in1) {
+      const float lx0 = wl::wl_cl_coef(i0 + 1, g.nx, cl.c[0]), lx1 = wl::wl_cl_coef(i0 + 2, g.nx, cl.c[0]), lx2 = wl::wl_cl_coef(i0 + 3, g.nx, cl.c[0]);
+      const float ly = wl::wl_cl_coef(j + 1, g.ny, cl.c[1]), lyp = wl::wl_cl_coef(j + 2, g.ny, cl.c[1]);
+      const float lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]), lzp = wl::wl_cl_coef(g.gk + k + 2, g.gnz, cl.c[2]);
+      const float xl = in0 ? x[o - 1] : 0.f, xr = in1 ? x[o + 2] : 0.f;
+      const float2 xym = pl_ld2(x, o - g.sy), xyp = pl_ld2(x, o + g.sy), xzm = pl_ld2(x, o - g.sz), xzp = pl_ld2(x, o + g.sz);
+      const float2 a0 = pl_ld2(uin, o), a1 = pl_ld2(uin, g.cs + o), a2 = pl_ld2(uin, 2 * g.cs + o);
+      const float axr = in1 ? uin[o + 2] : 0.f;
+      const float2 a1p = pl_ld2(uin, g.cs + o + g.sy), a2p = pl_ld2(uin, 2 * g.cs + o + g.sz);
+      // cell 0 (i0): same statements as k_project_cfl
+      const float uxn0 = a0.x - lx0 * (xc.x - xl), uxp0 = a0.y - lx1 * (xc.y - xc.x);
+      const float uyn0 = a1.x - ly * (xc.x - xym.x), uyp0 = a1p.x - lyp * (xyp.x - xc.x);
+      const float uzn0 = a2.x - lz * (xc.x - xzm.x), uzp0 = a2p.x - lzp * (xzp.x - xc.x);
+      // cell 1 (i0+1)
+      const float uxn1 = a0.y - lx1 * (xc.y - xc.x), uxp1 = axr - lx2 * (xr - xc.y);
+      const float uyn1 = a1.y - ly * (xc.y - xym.y), uyp1 = a1p.y - lyp * (xyp.y - xc.y);
+      const float uzn1 = a2.y - lz * (xc.y - xzm.y), uzp1 = a2p.y - lzp * (xzp.y - xc.y);
+      if (in0) { sg0 = 0.f; sg0 += (fmaxf(0.f, uxp0) + fmaxf(0.f, -uxn0)); sg0 += (fmaxf(0.f, uyp0) + fmaxf(0.f, -uyn0)); sg0 += (fmaxf(0.f, uzp0) + fmaxf(0.f, -uzn0)); }
+      if (in1) { sg1 = 0.f; sg1 += (fmaxf(0.f, uxp1) + fmaxf(0.f, -uxn1)); sg1 += (fmaxf(0.f, uyp1) + fmaxf(0.f, -uyn1)); sg1 += (fmaxf(0.f, uzp1) + fmaxf(0.f, -uzn1)); }
+      const float va[3] = {uxn0, uyn0, uzn0}, vb[3] = {uxn1, uyn1, uzn1};
+      const bool plain0 = !bc.on || wl_bc_fold_plain(g, i0, j, k), plain1 = !bc.on || wl_bc_fold_plain(g, i0 + 1, j, k);
+      if (in0 && in1 && plain0 && plain1) { pl_st2(uout, o, make_float2(va[0], vb[0])); pl_st2(uout, g.cs + o, make_float2(va[1], vb[1])); pl_st2(uout, 2 * g.cs + o, make_float2(va[2], vb[2])); }
+      else {
+        if (in0) { if (plain0) { uout[o] = va[0]; uout[g.cs + o] = va[1]; uout[2 * g.cs + o] = va[2]; } else wl_bc_fold_store(uout, g, i0, j, k, va, bc.U); }
+        if (in1) { if (plain1) { uout[o + 1] = vb[0]; uout[g.cs + o + 1] = vb[1]; uout[2 * g.cs + o + 1] = vb[2]; } else wl_bc_fold_store(uout, g, i0 + 1, j, k, vb, bc.U); }
+      }
+      if (store_sigma) { if (in0) sigma[o] = sg0; if (in1) sigma[o + 1] = sg1; }
+    }
+    if (want) {      // cells outside the interior: the stale Φ the reference leaves in σ's ghost cells takes part in maximum(σ)  (quirk Q1)
+      if (!in0) sg0 = sigma[o];
+      if (!in1) sg1 = sigma[o + 1];
+      mx = fmaxf(sg0, sg1);
+    }
+  }
+  mx = block_max(mx);
+  if (threadIdx.x == 0) atomicMax(reinterpret_cast<int*>(pmax) + (blockIdx.x & (WL_ENC_SLOTS - 1)), wl_enc_f(mx));
+}
+
 __global__ void k_fin_max_enc(const int* __restrict__ p, float* __restrict__ om) {
   float mx = -INFINITY;
   for (int q = threadIdx.x; q < WL_ENC_SLOTS; q += WL_BLOCK) { const int k = p[q]; if (k != (int)0x80000000) mx = fmaxf(mx, wl_dec_f(k)); }
@@ -1020,12 +1114,19 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
 }
 // linear block order (wl_tile_lin), one plane per block: bit 0 = the first projection tail (1.04 -> 0.875 ms at 512³), bit 1 = the second (project_cfl: SLOWER, 1.33 -> 1.55 ms — its
 // 13 loads per cell make it L1/L2-bound, not HBM-bound; the integer atomics are not the cause, profiles/r03_experiments.md).  Default 1.
+// two cells per thread in the linear-order tails: bit 0 = first tail, bit 1 = second tail (experiments: WL_TAIL_PAIR)
+static int tail_pair_bits() { static const int v = wl_exp_int("WL_TAIL_PAIR", 3); return v; }
+static int tail_pair() { return tail_pair_bits() & 1; }
 static int tail_lin(int bit) { static const int v = wl_exp_int("WL_TAIL_LIN", 1); return (v >> bit) & 1; }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold) {
   const int lin = tail_lin(0) && g.D == 3;
   const int zc = lin ? 1 : wl_march_chunk(g, g.nz);
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
+  if (tail_pair() && lin && cl.on && (g.nx & 1) == 0 && g.k0 >= 1) {   // two cells per thread (k_project_unscale2): x[o−sz] of plane 0 is never read (k0 >= 1)
+    hipLaunchKernelGGL(k_project_unscale2, dim3(pl_grid(g, g.nz)), dim3(WL_BLOCK), 0, s, g, u, x, pout, dt, cl, 0, g.nz, bc);
+    WL_LAUNCH_CHECK(); return 0;
+  }
   DSEL2(g.D, cl.on, k_project_unscale, wl_plane_grid(g, wl_march_slots(g.nz, zc)), dim3(WL_BLOCK), 0, s, g, u, L, x, pout, dt, cl, zc, 0, g.nz, bc, lin);
   WL_LAUNCH_CHECK(); return 0;
 }
@@ -1048,6 +1149,12 @@ int project_cfl(float* uout, const float* uin, const float* L, const float* x, f
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
+  if ((tail_pair_bits() & 2) && g.D == 3 && cl.on && (g.nx & 1) == 0 && g.k0 >= 1 && g.k1 <= g.nz - 1) {   // two cells per thread, linear order (k_project_cfl2)
+    hipLaunchKernelGGL(k_enc_init, dim3(1), dim3(WL_ENC_SLOTS), 0, s, reinterpret_cast<int*>(ws.pm));
+    hipLaunchKernelGGL(k_project_cfl2, dim3(pl_grid(g, g.nz)), dim3(WL_BLOCK), 0, s, g, uout, uin, x, pout, sigma, dt, cl, kfirst, klast, ws.pm, 0, g.nz, store_sigma, bc);
+    hipLaunchKernelGGL(k_fin_max_enc, dim3(1), dim3(WL_BLOCK), 0, s, reinterpret_cast<const int*>(ws.pm), ws.res_f + slot_f);
+    WL_LAUNCH_CHECK(); return 0;
+  }
   const int lin = tail_lin(1) && g.D == 3;
   const int zc = lin ? 1 : wl_march_chunk(g, g.nz);
   const dim3 grid = wl_plane_grid(g, wl_march_slots(g.nz, zc));
