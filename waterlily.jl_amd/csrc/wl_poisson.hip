@@ -1112,10 +1112,11 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(WL_BLOCK), 0, s, ws.pa, off, ws.res_d + 0);
   WL_LAUNCH_CHECK(); return 0;
 }
-// linear block order (wl_tile_lin), one plane per block: bit 0 = the first projection tail (1.04 -> 0.875 ms at 512³), bit 1 = the second (project_cfl: SLOWER, 1.33 -> 1.55 ms — its
-// 13 loads per cell make it L1/L2-bound, not HBM-bound; the integer atomics are not the cause, profiles/r03_experiments.md).  Default 1.
-// two cells per thread in the linear-order tails: bit 0 = first tail, bit 1 = second tail (experiments: WL_TAIL_PAIR)
-static int tail_pair_bits() { static const int v = wl_exp_int("WL_TAIL_PAIR", 3); return v; }
+// Block order of the projection tails (experiments: WL_TAIL_LIN / WL_TAIL_PAIR in a -DWL_EXPERIMENTS build; profiles/r03_experiments.md §4, §8):
+//   first tail (k_project_unscale): linear block order, one plane per block, one cell per thread — 1.04 -> 0.875 ms at 512³ (two cells per thread: 0.915);
+//   second tail (+ flux_out + max σ): in linear order the one-cell kernel is L1-bound (13 dword loads per cell: 1.33 -> 1.55 ms), with two cells per
+//   thread (k_project_cfl2, ≈6.5 loads per cell) linear order wins: 1.34 -> 1.18 ms.
+static int tail_pair_bits() { static const int v = wl_exp_int("WL_TAIL_PAIR", 2); return v; }     // bit 0: first tail, bit 1: second tail
 static int tail_pair() { return tail_pair_bits() & 1; }
 static int tail_lin(int bit) { static const int v = wl_exp_int("WL_TAIL_LIN", 1); return (v >> bit) & 1; }
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold) {
