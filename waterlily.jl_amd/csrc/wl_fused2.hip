@@ -71,3 +71,13 @@ int gsrb_pair_B(float* eps, float* rout, float* x, const float* emid, const floa
   return rows16(g, 2) ? pair16::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s, xd) : pair32::gsrb_pair_B(eps, rout, x, emid, r, g, w, ws, slot_d, slot_f, cl, s, xd);
 }
 }  // namespace wl
+
+#ifdef WL_STAMP
+// diagnostic build: per-wave cycle sums of kernel A's fast steps (pair32 instance) — [pre-barrier, barrier wait, sweeps, stores, steps]
+extern "C" int wl_debug_stamps(unsigned long long* out5, int reset) {
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(out5, HIP_SYMBOL(pair32::g_wl_stamp), 5 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(pair32::g_wl_stamp), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+}
+#endif
