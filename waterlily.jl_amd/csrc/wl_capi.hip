@@ -29,6 +29,29 @@ int wl_ctx_ensure() {
 }
 
 long g_wl_launches = 0;
+// two auxiliary streams for launches that are independent of each other (plane ranges of a level with a body): fork/join with events
+namespace wl {
+namespace { hipStream_t g_par[2] = {nullptr, nullptr}; hipEvent_t g_par_fork = nullptr, g_par_join[2] = {nullptr, nullptr}; int g_par_state = 0; }
+bool par_streams_ok() {
+  if (g_par_state == 0) {
+    g_par_state = -1;
+    if (hipStreamCreateWithFlags(&g_par[0], hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&g_par[1], hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&g_par_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&g_par_join[0], hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&g_par_join[1], hipEventDisableTiming) == hipSuccess) g_par_state = 1;
+  }
+  return g_par_state == 1;
+}
+hipStream_t par_stream(int i) { return g_par[i]; }
+int par_fork(hipStream_t s) {
+  WL_HIP(hipEventRecord(g_par_fork, s));
+  WL_HIP(hipStreamWaitEvent(g_par[0], g_par_fork, 0)); WL_HIP(hipStreamWaitEvent(g_par[1], g_par_fork, 0));
+  return 0;
+}
+int par_join(hipStream_t s) {
+  for (int i = 0; i < 2; i++) { WL_HIP(hipEventRecord(g_par_join[i], g_par[i])); WL_HIP(hipStreamWaitEvent(s, g_par_join[i], 0)); }
+  return 0;
+}
+}  // namespace wl
 WlProf& wl_prof() { static WlProf p; return p; }
 ProfScope::ProfScope(int id_, hipStream_t s_) : id(id_), s(s_), active(false), idx(0) {
   WlProf& p = wl_prof();
@@ -191,29 +214,41 @@ int wl_mg::smooth(int l, int it, float w, hipStream_t s, bool want_norms, bool* 
     p.pend = false;
     bool xdef[3] = {false, false, false};                    // per range: `x += ω·x_c↓` handed from kernel A to kernel B (wl::XDefer)
     const wl::XDefer xd{coarse.x, coarse.x_, w};
+    // The three plane ranges write disjoint planes and read only what the previous phase left: their launches are independent, and each of them is a
+    // latency-bound march on an under-filled chip (sphere 256³: 35–76 µs each).  They run concurrently on the main stream and two auxiliary streams
+    // (fork: the aux streams wait for an event of the main stream; join: the main stream waits for theirs); kernel B needs ALL of kernel A's ranges
+    // (its halo reaches across the cuts): one join between the two phases.  Partial norms of the ranges land in disjoint thirds of the workspace.
+    const bool par = par_ranges && wl::par_streams_ok() && (long)p.g.nx * p.g.ny <= 520L * 520L;
+    hipStream_t sr[3] = {s, par ? wl::par_stream(0) : s, par ? wl::par_stream(1) : s};
     {
       ProfScope pa(l == 0 ? WL_PROF_GS_A : -1, s);
+      if (par) WL_TRY(wl::par_fork(s));
       for (int i = 0; i < 3; i++) if (parts[i].b > parts[i].a) {
         const GridX g = sub(parts[i].a, parts[i].b);
         if (pro) {
           xdef[i] = use_xdefer && wl::gsrb_pair_B_ok(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, g, *parts[i].cl);
           if (l == 0) last_xdefer = xdef[i] ? 1 : 0;
-          WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, g, coarse.x_, w, *parts[i].cl, s, -(1 << 30), 1 << 30, &xdef[i]));
-        } else WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, g, *parts[i].cl, s));
+          WL_TRY(wl::gsrb_fused_A_pro(p.em, p.rs, p.x, p.r, coarse.x, p.L, g, coarse.x_, w, *parts[i].cl, sr[i], -(1 << 30), 1 << 30, &xdef[i]));
+        } else WL_TRY(wl::gsrb_fused_A(p.em, p.r, p.L, g, *parts[i].cl, sr[i]));
       }
+      if (par) WL_TRY(wl::par_join(s));
     }
     {
       ProfScope pb(l == 0 ? WL_PROF_GS_B : -1, s);
       // L₁/L∞ of the new residual: every range leaves its own pair in a slot of its own (res_d[2|5|6], res_f[1|2|3]); solver! adds them
       static const int SD[3] = {2, 5, 6}, SF[3] = {1, 2, 3};
       norm_slots = 0;
+      if (par) WL_TRY(wl::par_fork(s));
       for (int i = 0; i < 3; i++) if (parts[i].b > parts[i].a) {
         const GridX g = sub(parts[i].a, parts[i].b);
-        const RedWs* nws = want_norms ? &ws : nullptr;
+        RedWs wsi = ws;
+        if (par) { wsi.pa += (size_t)i * (WL_MAXPART / 3); wsi.pm += (size_t)i * (WL_MAXPART / 3); }
+        const RedWs* nws = want_norms ? &wsi : nullptr;
         if (want_norms) norm_slots |= 1 << i;
-        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s, xdef[i] ? &xd : nullptr));
-        else WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, s));
+        if (pro) WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.r, p.x, p.em, p.rs, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, sr[i], xdef[i] ? &xd : nullptr));
+        else WL_TRY(wl::gsrb_fused_B(store_eps ? p.eps : nullptr, p.rs, p.x, p.em, p.r, p.L, g, w, nws, SD[i], SF[i], *parts[i].cl, sr[i]));
       }
+      if (par) WL_TRY(wl::par_join(s));
     }
     if (!pro) std::swap(p.r, p.rs);
     if (norms_done) *norms_done = want_norms;

@@ -281,6 +281,7 @@ int div_residual_split(float* z, float* xout, float* r, const float* x, const fl
                        const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);
 // fused head of mom_project! + the V-cycle's first Jacobi! on the finest level (wl_resjac.hip)
 void resjac_enable(int on, long min_cells);
+bool par_streams_ok(); hipStream_t par_stream(int i); int par_fork(hipStream_t s); int par_join(hipStream_t s);   // wl_capi.hip
 bool resjac_ok(const GridX& g, const ConstL& cl);
 int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s,
            bool shell = true);   // shell = false: x's (and x_out's) ghost cells are known to be +0 — the ghost-shell scaling pass is skipped

@@ -33,6 +33,7 @@ struct wl_mg {
   bool deep_halo = true;     // z-slabs with >= 5 ghost planes: one r exchange (5 planes) per smooth! instead of r (2) + ϵ_mid (3) + r' (2)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
+  bool par_ranges = false;  // levels with a body: the plane ranges of the z-split on concurrent streams (wl::par_fork / par_join) — measured SLOWER (sphere 256³ 2.84 -> 3.07 ms: the fork/join events cost more than the overlap of 35–76 µs launches returns); "zsplit_par" turns it on
   int x_halo_depth = 1;     // z-slabs: ghost planes of x refreshed at the end of solver! (the projection tail reads 1; the fused projection head of the NEXT solve reads 2)
   int last_xdefer = -1;     // what the finest level's last smooth! with a pending prolongation decided: 1 = x += ω·x_c↓ deferred to kernel B, 0 = applied by kernel A (−1: none yet)
   bool use_xdefer = true;   // pair smoother: the V-cycle's `x += ω·x_c↓` is applied by kernel B together with its own increment (wl::XDefer)

@@ -751,6 +751,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
+  if (n == "zsplit_par") { s->mg->par_ranges = value != 0; return 0; }
   if (n == "itmx") { if (value < 1) { wl_set_error("itmx must be >= 1"); return WL_EINVAL; } s->itmx = value; return 0; }
   wl_set_error("unknown option " + n); return WL_EINVAL;
 }
