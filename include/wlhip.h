@@ -277,6 +277,9 @@ int wl_comm_set_loopback(wl_comm* c, int on);
  * what it measures on ONE GPU is the rank's compute per step, its exchange rounds/bytes, and the issue cost of the RCCL calls
  * (tools/slab_rank_bench.py -> profiles/r03_slab8_rank_compute.json).  Call right after wl_comm_rccl_create (+ _add_async). */
 int wl_comm_set_virtual(wl_comm* c, int rank, int size);
+/* rehearsal transport: 1 (default) = every exchange goes through RCCL to this rank itself; 0 = no transfer at all (ghost planes keep what they hold):
+ * the difference between the two runs is what issuing the exchanges costs on this box, the second is the rank's pure compute */
+int wl_comm_set_virtual_transport(wl_comm* c, int on);
 /* z-periodic domain on z-slabs: the halo exchanges wrap around (rank 0's lower neighbour is the last rank).  wl_sim_create sets it from the
  * descriptor's perdir mask; callback transports get both neighbours on every rank and must address them modulo the size. */
 int wl_comm_set_periodic(wl_comm* c, int on);

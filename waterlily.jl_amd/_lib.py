@@ -135,6 +135,7 @@ SIGNATURES = {
     "wl_comm_rccl_add_async": (i32, [P, C.c_char_p]),
     "wl_comm_set_loopback": (i32, [P, i32]),
     "wl_comm_set_virtual": (i32, [P, i32, i32]),
+    "wl_comm_set_virtual_transport": (i32, [P, i32]),
     "wl_comm_set_periodic": (i32, [P, i32]),
     "wl_comm_halo_async": (i32, [P, P, G, i32, i32, P]),
     "wl_comm_combine_test": (i32, [P, P, P, P]),

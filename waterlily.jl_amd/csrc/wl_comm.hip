@@ -70,8 +70,8 @@ struct RcclComm : wl_comm {
   ncclComm_t comm = nullptr, comm_async = nullptr;
   int depth = 0;
   ~RcclComm() override { if (comm_async) (void)rccl().CommDestroy(comm_async); if (comm) (void)rccl().CommDestroy(comm); }
-  int group_begin() override { gdepth++; if (depth++ == 0) WL_NCCL(rccl().GroupStart()); return 0; }
-  int group_end() override { if (gdepth > 0) gdepth--; if (depth > 0 && --depth == 0) WL_NCCL(rccl().GroupEnd()); return 0; }
+  int group_begin() override { gdepth++; if (virt && virt_null) return 0; if (depth++ == 0) WL_NCCL(rccl().GroupStart()); return 0; }
+  int group_end() override { if (gdepth > 0) gdepth--; if (virt && virt_null) return 0; if (depth > 0 && --depth == 0) WL_NCCL(rccl().GroupEnd()); return 0; }
   int sendrecv_body(ncclComm_t cm, const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) {
     // neighbours: lo = rank-1, hi = rank+1 (loopback: both are this rank — what it sends down comes back as its upper ghost planes and
     // vice versa, the z-periodic wrap; sends and receives to one peer match in issue order, hence lo-send / hi-recv first)
@@ -85,6 +85,7 @@ struct RcclComm : wl_comm {
     return 0;
   }
   int sendrecv(const void* slo, void* rlo, const void* shi, void* rhi, size_t bytes, hipStream_t s) override {
+    if (virt && virt_null) return 0;
     WL_TRY(group_begin());
     ncclComm_t cm = (comm_async && s == cs && cs) ? comm_async : comm;
     const int rc = sendrecv_body(cm, slo, rlo, shi, rhi, bytes, s);
@@ -92,6 +93,7 @@ struct RcclComm : wl_comm {
     return rc ? rc : re;
   }
   int allgather(const void* send, void* recv, size_t bytes_each, hipStream_t s) override {
+    if (virt && virt_null) return 0;
     if (virt) {   // rehearsal: the one-rank all-gather lands in this rank's block; the other ranks' blocks are filled with copies of it (every pretended rank = this slab)
       char* mine = (char*)recv + (size_t)rank * bytes_each;
       WL_NCCL(rccl().AllGather(send, mine, bytes_each, ncclChar, comm, s));
@@ -212,6 +214,7 @@ int wl_comm_set_virtual(wl_comm* cc, int rank, int size) {
   c->virt = true; c->real_rank = c->rank; c->real_size = c->size; c->rank = rank; c->size = size;
   return 0;
 }
+int wl_comm_set_virtual_transport(wl_comm* c, int on) { WL_CHECK(c && c->virt, "not a communicator in rehearsal mode"); c->virt_null = on == 0; return 0; }
 int wl_comm_set_loopback(wl_comm* c, int on) { WL_CHECK(c && c->size == 1, "loopback is a one-rank test mode"); c->loopback = on != 0; return 0; }
 int wl_comm_halo_async(wl_comm* c, float* a, const wl_grid* g, int ncomp, int depth, void* st) {
   WL_CHECK(g && g->D == 3, "halo exchange needs a 3-D slab grid");

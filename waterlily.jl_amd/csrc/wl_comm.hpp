@@ -10,6 +10,7 @@ struct wl_comm {
   // pattern follow them — while the transport underneath has one rank: planes sent to a neighbour come back as this rank's own ghost planes.
   // What one GPU can measure of a P-GPU step: the rank's compute, the number and size of its exchanges, the issue cost of the RCCL calls.
   bool virt = false; int real_rank = 0, real_size = 1;
+  bool virt_null = false;   // rehearsal without any transfer (wl_comm_set_virtual_transport(c,0)): exchanges and all-gathers return at once — the rank's pure compute
   void* gather = nullptr;   // device scratch for scalar all-gathers: size * 128 bytes
   virtual ~wl_comm();
   // lo neighbour = rank-1, hi neighbour = rank+1; pointers are NULL where there is no neighbour
