@@ -22,8 +22,8 @@ int wl_prof_read(int slot, int* host_count, double* host_total_ms);   /* synchro
 
 /* kernel launches issued by the library in this process so far (every hipLaunchKernelGGL of libwlhip; copies and memsets are not counted) */
 long wl_launch_count(void);
-/* wl_sim_create on a large 3-D grid whose arrays the handle owns tries several placements of its allocations and keeps the fastest
- * (see wl_sim.hip "Placement trials"; WL_PLACEMENT_TRIALS=1 disables): the candidates' scores (ms of a timed mom_project! pair on zero fields) */
+/* With WL_PLACEMENT_TRIALS=2…8 (default 1 = off) wl_sim_create on a large 3-D grid whose arrays the handle owns tries that many placements of its
+ * allocations and keeps the fastest (wl_sim.hip "Placement trials" — measured: not a reliable remedy): the candidates' scores, ms of a timed mom_project! pair */
 int wl_placement_scores(double* out, int cap);
 /* per-handle path counters: "resjac" = solves whose fused projection head (div + x·dt + residual! + first Jacobi!) stood,
  * "resjac_redo" = solves where residual!'s mean shift was due after all and the head was redone on the two-kernel path,

@@ -642,7 +642,10 @@ static int sim_create_common(wl_sim** out, const wl_sim_desc* desc, wl_comm* com
 // one after the other: profiles/r03_placement_trial.txt; a plain z-marching copy: 3.6 vs 4.7 TB/s, profiles/r03_place_probe2.txt) — element-wise
 // kernels do not care.  A handle that owns all its arrays therefore creates up to `trials` candidates (each in new memory: the others are held meanwhile),
 // times mom_project! once on each (zero fields: every kernel of the projection runs, nothing changes) and keeps the fastest.  Results are placement-
-// independent; only large grids take part (small ones live in the caches).  WL_PLACEMENT_TRIALS=1 switches it off.
+// independent; only large grids take part (small ones live in the caches).
+// OFF by default (WL_PLACEMENT_TRIALS=1; set it to 2…8 to try): six default bench runs with 6 candidates against six without (profiles/r03_bench_distribution.txt) —
+// mean step 9.88 vs 9.89 ms, the smoother pair in its fast state in 2 of 6 vs 3 of 6 runs.  Candidates allocated after the first one are rarely in the fast state,
+// so holding memory to force new placements buys almost nothing; the finding (placement decides 7–12 % of the pair) stands, the remedy does not work.
 static double placement_score(wl_sim* s) {
   hipStream_t q = 0;
   const size_t n0 = s->mg->n.size();
@@ -667,7 +670,7 @@ static double placement_score(wl_sim* s) {
 static double g_last_placement[8]; static int g_last_placement_n = 0;
 int wl_sim_create(wl_sim** out, const wl_sim_desc* desc) {
   WL_CHECK(out && desc, "null pointer");
-  static const int trials_env = [] { const char* e = getenv("WL_PLACEMENT_TRIALS"); const int v = e ? atoi(e) : 6; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
+  static const int trials_env = [] { const char* e = getenv("WL_PLACEMENT_TRIALS"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 8 ? 8 : v); }();
   const bool owned = !desc->u && !desc->u0 && !desc->f && !desc->p && !desc->sigma && !desc->V && !desc->mu0 && !desc->mu1 && !desc->us;
   const long cells = (long)desc->dims[0] * desc->dims[1] * (desc->D == 3 ? desc->dims[2] : 1);
   int trials = (owned && desc->D == 3 && cells >= (48L << 20)) ? trials_env : 1;      // (≥ 48 Mi cells: the arrays are far larger than the Infinity Cache)
