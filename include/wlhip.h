@@ -200,13 +200,14 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[6 Mi cells] size gate (tests: 0)
+   "convf"[1] the tiled conv_diff!+BDIM! evaluates every face flux once (wl_convf.hip); 0: the two-cells-per-thread kernel that re-evaluates upper faces
    "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0)
    "xdefer"[1] pair smoother: the V-cycle's x += ω·x_c↓ is applied by kernel B together with its own increment (x makes one round trip per smooth!)
    "tail_lds"[1] the single-launch coarse tail keeps r, x, ϵ of its levels in LDS (0: in global memory)
    "body_tile"[1] with a body: conv_diff!+BDIM! on the body-free plane ranges through the tiled NoBody kernel ("convt")
    "itmx"[32] solver!'s iteration cap `itmx` (src/MultiLevelPoisson.jl:108) */
 int wl_sim_set_option(wl_sim* s, const char* name, int value);
-/* "resjac_min", "convt_min", "convt", "tail_lds", "body_tile", "pair", "jacobi_march", "convm" (and wl_mg_set_fused bits 2 and 5) are PROCESS-wide:
+/* "resjac_min", "convt_min", "convt", "convf", "tail_lds", "body_tile", "pair", "jacobi_march", "convm" (and wl_mg_set_fused bits 2 and 5) are PROCESS-wide:
    they choose between kernels that produce identical bits, for every handle of the process.  wl_reset_process_options() restores their defaults. */
 int wl_reset_process_options(void);
 /* time-dependent but spatially uniform boundary velocity / body force: the host evaluates uBC(i,t₁) and

@@ -892,9 +892,10 @@ def test_moments_2d_hydrostatic(w, oracle):
 @pytest.mark.parametrize("dims", [(64, 32, 24), (128, 48, 11), (72, 24, 40), (52, 36, 20), (130, 34, 16), (36, 20, 12)])
 @pytest.mark.parametrize("lam", [0, 1, 2])
 def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
-    """predictor and corrector (conv_diff!+BDIM!, NoBody) through the LDS-tiled z-marching kernel (wl_convt.hip: two cells per
-    thread, fluxes shared between neighbouring cells, z-face flux carried from plane to plane) vs the oracle and vs the plane
-    kernel: u bit for bit.  Shapes: whole tiles (64·a × 16·b) and ragged ones (tiles cut by the boundary in x and y, pairs
+    """predictor and corrector (conv_diff!+BDIM!, NoBody) through the LDS-tiled z-marching kernels — wl_convf.hip (default: every face
+    flux evaluated once; upper faces come from the next lane, from the row above through LDS, and from one generic flux per thread
+    on the tile's upper edges) and wl_convt.hip (convf=0: two cells per thread, upper faces re-evaluated) — vs the oracle and vs the
+    plane kernel: u bit for bit.  Shapes: whole tiles (64·a × 16·b) and ragged ones (tiles cut by the boundary in x and y, pairs
     straddling the last column), several z-chunks (the test threshold makes chunks of 5 planes), QUICK / vanLeer / CDS."""
     if lam == 1 and dims not in ((64, 32, 24), (52, 36, 20)):
         pytest.skip("vanLeer: two shapes are enough")
@@ -907,28 +908,32 @@ def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
     so.field("u")[...] = u_init
     so.field("u0")[...] = u_init
     res = {}
-    for convt in (1, 0):
+    for mode, (convt, convf) in {"flux": (1, 1), "tile": (1, 0), "plane": (0, 1)}.items():
         sg = w.FusedSimulation(dims, (1.0, 0.0, 0.0), dims[0], U=1, nu=nu, u0=u_init, lam=lam)
         sg.set_option("convt", convt)
+        sg.set_option("convf", convf)
         sg.set_option("convt_min", 0)
         out = []
         for ph in (0, 1, 2, 3):
             sg.phase_(ph)
             if ph in (1, 3):
                 out.append(sg.field("u"))
-        res[convt] = out
+        res[mode] = out
         sg.set_option("convt_min", 8192)
         sg.set_option("convt", 1)
+        sg.set_option("convf", 1)
     outo = []
     for ph in (0, 1, 2, 3):
         so.phase(ph)
         if ph in (1, 3):
             outo.append(so.field("u").copy())
-    assert np.array_equal(res[0][0], outo[0]), "plane kernel vs oracle (predictor)"
-    assert np.array_equal(res[1][0], outo[0]), "tiled kernel vs oracle (predictor)"
-    # the corrector's input went through a pressure solve (reductions): the two HIP paths must still agree exactly
-    assert np.array_equal(res[1][1], res[0][1]), "tiled vs plane kernel (corrector)"
-    assert np.abs(res[1][1] - outo[1]).max() < 2e-5
+    assert np.array_equal(res["plane"][0], outo[0]), "plane kernel vs oracle (predictor)"
+    assert np.array_equal(res["flux"][0], outo[0]), "flux-once kernel vs oracle (predictor)"
+    assert np.array_equal(res["tile"][0], outo[0]), "tiled kernel vs oracle (predictor)"
+    # the corrector's input went through a pressure solve (reductions): the HIP paths must still agree exactly
+    assert np.array_equal(res["flux"][1], res["plane"][1]), "flux-once vs plane kernel (corrector)"
+    assert np.array_equal(res["tile"][1], res["plane"][1]), "tiled vs plane kernel (corrector)"
+    assert np.abs(res["flux"][1] - outo[1]).max() < 2e-5
 
 
 @pytest.mark.parametrize("dims", [(64, 32, 24), (96, 64, 40), (70, 44, 18), (128, 36, 12)])

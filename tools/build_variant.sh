@@ -10,7 +10,7 @@ cd "$(dirname "$0")/../waterlily.jl_amd/csrc"
 make -j8 >/dev/null
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result"
 OBJS=""
-for f in wl_flow wl_poisson wl_capi wl_sim wl_comm wl_fused wl_fused2 wl_convz wl_convm wl_convt wl_resjac; do
+for f in wl_flow wl_poisson wl_capi wl_sim wl_comm wl_fused wl_fused2 wl_convz wl_convm wl_convt wl_convf wl_resjac; do
   if [[ " $FILES " == *" $f.hip "* ]]; then
     /opt/rocm/bin/hipcc $FLAGS $EXTRA -c $f.hip -o /tmp/${f}_$NAME.o
     OBJS="$OBJS /tmp/${f}_$NAME.o"

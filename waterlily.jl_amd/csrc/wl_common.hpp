@@ -247,6 +247,10 @@ void conv_tile_enable(int on, int chunk);
 void conv_tile_min(long tile_planes);
 bool conv_tile_ok(const GridX& g, unsigned per, int nplanes);
 int conv_tile(const float* u_adv, const GridX& g, float nu, int scheme, int ka, int kb, const void* bdim_args, hipStream_t s);
+// the flux-once form of the tiled kernel (wl_convf.hip); conv_tile dispatches to it unless conv_flux_enable(0)
+void conv_flux_enable(int on);
+bool conv_flux_on();
+int conv_flux(const float* u_adv, const GridX& g, float nu, int scheme, int ka, int kb, int zchunk, const void* bdim_args, hipStream_t s);
 void conv_march_enable(int on);
 void jacobi_march_enable(int on);
 bool conv_march_ok(const GridX& g);

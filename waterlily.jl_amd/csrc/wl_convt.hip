@@ -349,6 +349,7 @@ int conv_tile(const float* u_adv, const GridX& g, float nu, int scheme, int ka, 
   if (zc <= 0) { long t = (long)np * ntiles / 1024; zc = (int)(t < 5 ? 5 : (t > 64 ? 64 : t)); }   // ≈1024 workgroups (512 resident); small boxes: short chunks (128³: 0.62 -> 0.58 ms/step with 5 planes instead of 16)
   if (g_convt_min == 0 && !g_convt_chunk && !envc) zc = 5;   // tests: several chunks on a small box
   if (zc > np) zc = np;
+  if (conv_flux_on()) return conv_flux(u_adv, g, nu, scheme, ka, kb, zc, bdp, s);   // every flux once (wl_convf.hip); this kernel stays as the A/B reference (option convf=0)
   const int nch = (np + zc - 1) / zc;
   const dim3 grid((unsigned)(8 * per * nch), 1, 1);
   const bool full = (g.nx - 2) % CT_CX == 0 && (g.ny - 2) % CT_CY == 0;

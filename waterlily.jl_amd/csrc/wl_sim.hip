@@ -751,6 +751,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "convf") { wl::conv_flux_enable(value != 0); return 0; }                            // 1: tiled conv_diff! evaluates every flux once (default), 0: k_conv_tile
   if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
   if (n == "fuse_p") { s->use_fuse_p = value != 0; return 0; }
@@ -763,7 +764,7 @@ int wl_sim_update(wl_sim* s, void* st) { s->resjac_backoff = false; s->resjac_re
 long wl_launch_count(void) { return g_wl_launches; }
 // the size gates and kernel-family switches that wl_sim_set_option / wl_mg_set_fused keep PROCESS-wide (they select code, not results): back to the defaults
 int wl_reset_process_options(void) {
-  wl::resjac_enable(1, 6L << 20); wl::conv_tile_min(2048); wl::conv_tile_enable(1, 0); wl::tail_lds_enable(1); wl::conv_body_tile_enable(1);
+  wl::resjac_enable(1, 6L << 20); wl::conv_tile_min(2048); wl::conv_tile_enable(1, 0); wl::conv_flux_enable(1); wl::tail_lds_enable(1); wl::conv_body_tile_enable(1);
   wl::gsrb_pair_enable(1); wl::jacobi_march_enable(1); wl::conv_march_enable(0);
   return 0;
 }
