@@ -200,6 +200,9 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[6 Mi cells] size gate (tests: 0)
+   "tailfuse"[0] wl_sim_mom_step: the first projection's tail (u −= L∇x, BC!) is evaluated by the corrector's conv_diff! loader; the projected predictor
+       velocity is never written (whole tiles, single domain, tuple U, no periodic direction / exit / body; results identical; measured: no gain, hence off).
+       wl_sim_phase always keeps the tail launch.
    "convf"[1] the tiled conv_diff!+BDIM! evaluates every face flux once (wl_convf.hip); 0: the two-cells-per-thread kernel that re-evaluates upper faces
    "convt_min"[2048] tile-planes below which "convt" leaves the launch to the plane kernel (tests: 0)
    "xdefer"[1] pair smoother: the V-cycle's x += ω·x_c↓ is applied by kernel B together with its own increment (x makes one round trip per smooth!)

@@ -936,6 +936,43 @@ def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
     assert np.abs(res["flux"][1] - outo[1]).max() < 2e-5
 
 
+@pytest.mark.parametrize("dims", [(64, 32, 24), (128, 48, 16), (64, 16, 12), (192, 32, 9)])
+@pytest.mark.parametrize("uBC,lam", [((1.0, 0.0, 0.0), 0), ((0.3, -0.2, 0.1), 0), ((0.3, -0.2, 0.1), 2), ((1.0, 0.0, 0.0), 1)])
+def test_deferred_projection_is_bit_identical(w, oracle, dims, uBC, lam):
+    """mom_step! with the first projection's tail (u −= L∇x, then BC!) evaluated by the corrector's conv_diff! loader (wl_convf.hip, PROJ: the
+    projected predictor velocity is never written) against the step with the separate tail launch — u, u⁰, p, pois.n, Δt bit for bit on every
+    cell after three steps, wall tiles and interior tiles, several z-chunks, tuple U with all components nonzero — and against the oracle."""
+    if lam == 1 and dims != (64, 32, 24):
+        pytest.skip("vanLeer: one shape is enough")
+    rng = np.random.default_rng(61)
+    Ng = tuple(n + 2 for n in dims)
+    u_init = np.asfortranarray(rng.uniform(-0.4, 0.4, size=Ng + (3,)).astype(np.float32))
+    so = oracle.Simulation(dims, uBC, dims[0], U=1, nu=0.02, T=np.float32, scheme=lam)
+    oracle.BC(u_init, uBC)
+    so.field("u")[...] = u_init
+    so.field("u0")[...] = u_init
+    res = {}
+    for fuse in (1, 0):
+        sg = w.FusedSimulation(dims, uBC, dims[0], U=1, nu=0.02, u0=u_init, lam=lam)
+        sg.set_option("tailfuse", fuse)
+        sg.set_option("convt_min", 0)
+        sg.set_option("resjac_min", 0)
+        for _ in range(3):
+            sg.mom_step_()
+        res[fuse] = (sg.field("u"), sg.field("u0"), sg.field("p"), sg.pois_n, sg.dt)
+        assert sg.counter("tailfuse") == (3 if fuse else 0)
+        sg.set_option("convt_min", 8192)
+        sg.set_option("resjac_min", 8 << 20)
+    for _ in range(3):
+        so.step(remeasure=False)
+    assert res[1][3] == res[0][3] and res[1][4] == res[0][4]
+    for q in range(3):
+        assert np.array_equal(res[1][q], res[0][q]), ("u", "u0", "p")[q]
+        assert np.array_equal(np.signbit(res[1][q]), np.signbit(res[0][q])), ("sign of zero", ("u", "u0", "p")[q])
+    assert res[1][3] == so.pois_n
+    assert np.abs(res[1][0] - so.u).max() < 5e-5 and np.abs(res[1][2] - so.p).max() < 5e-4
+
+
 @pytest.mark.parametrize("dims", [(64, 32, 24), (96, 64, 40), (70, 44, 18), (128, 36, 12)])
 def test_fused_projection_head_is_bit_identical(w, oracle, dims):
     """mom_project!'s head (z=∇·u, x·=dt, residual!) and the V-cycle's first Jacobi! in ONE z-marching kernel (wl_resjac.hip), assuming

@@ -200,7 +200,9 @@ struct ProfScope {   // RAII: records start at construction and stop at destruct
 };
 
 // BC!(u,U) for a tuple U folded into a producer's stores (wl_bcfold.hpp): request (on = 1, U) / report (on = 1 if it was applied)
-struct BcFold { int on; float U[3]; };
+struct BcFold { int on; float U[3];
+                // in: x of a projection whose velocity update was deferred to this conv_diff! launch (wl_convf.hip, PROJ); out: 1 = the launch applied it
+                const float* proj_x = nullptr; int proj_done = 0; };
 
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {
@@ -219,6 +221,7 @@ int const_plane_range(const float* L, const GridX& g, const float* c, int* za, i
 int fill(float* a, float v, size_t n, hipStream_t s);
 int scale(float* a, float s_, size_t n, hipStream_t s);
 int div_scalar(float* a, float s_, size_t n, hipStream_t s);
+int div_scalar_to(float* out, const float* in, float s_, size_t n, hipStream_t s);
 // reductions leave results in ws.res_d / ws.res_f on device; *_host variants copy to host & sync
 int sum_dev(const float* a, size_t n, const RedWs& ws, int slot, hipStream_t s);
 int l1_linf_dev(const float* a, size_t n, const RedWs& ws, int slot_d, int slot_f, hipStream_t s);
@@ -250,6 +253,7 @@ int conv_tile(const float* u_adv, const GridX& g, float nu, int scheme, int ka, 
 // the flux-once form of the tiled kernel (wl_convf.hip); conv_tile dispatches to it unless conv_flux_enable(0)
 void conv_flux_enable(int on);
 bool conv_flux_on();
+bool conv_proj_ok(const GridX& g, unsigned per);   // geometry of the fused projection: whole tiles, whole single domain
 int conv_flux(const float* u_adv, const GridX& g, float nu, int scheme, int ka, int kb, int zchunk, const void* bdim_args, hipStream_t s);
 void conv_march_enable(int on);
 void jacobi_march_enable(int on);

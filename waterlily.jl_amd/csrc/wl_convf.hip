@@ -84,7 +84,14 @@ int g_convf_on = 1;
 
 // MODE: how BDIM!'s u_out = (u·pre + μ₀·f)·post is evaluated — 1: pre = 0 and post = 1 (predictor: u_out = 0 + μ₀·f), 2: pre ≠ 0 and post ≠ 1
 // (corrector), 0: decided at run time per value (two selects per value: 5 % of the kernel's vector instructions).  Same arithmetic in all three.
-template <int SCH, int FULL, int U0ADV, int MODE>
+// PROJ: the advecting field is read through mom_project!'s tail and BC! (src/Flow.jl:227-230, src/core.jl:200-219): u holds the UNPROJECTED
+// predictor velocity u*, bd.px the solver's x (pressure·Δt); every value that enters the LDS planes is
+//     U_a                                   where component a is normal to a boundary face (index 0, 1, N−1 along a),
+//     u*_a[c] − c_a·(x[c] − x[c−δa])        elsewhere, c = the cell with the two other coordinates clamped into the interior
+// — the statements of k_project_unscale (constant coefficients: L = c_a away from the wall faces) followed by BC!'s closed form for a tuple U
+// (wl_bcfold.hpp), so the values are bit for bit those the separate tail + BC! launches would have left in memory; the projected predictor
+// velocity is never written (−24 B/cell of the step's traffic and one launch).  FULL tiles, single domain, no periodic direction / exit / body.
+template <int SCH, int FULL, int U0ADV, int MODE, int PROJ>
 __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __restrict__ u, float nu, int ka, int kb, int zchunk, BdimArgs bd) {
   __shared__ float lds[CF_LDS];
   const int ntx = (g.nx - 2 + CF_CX - 1) / CF_CX, nty = (g.ny - 2 + CF_CY - 1) / CF_CY;
@@ -128,21 +135,64 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
   __syncthreads();
 
   struct Stage { float2 c[3]; float2 h; };
-  // planes outside the local array (k = −1 below the first plane, nz above the last) are never used either: clamp
+  // PROJ: the two elements of the halo pair are loaded one by one from the cells their BC!-clamped coordinates name
+  unsigned ho[2] = {0u, 0u}, hnb = 0u; bool hd[2] = {false, false}; float hU = 0.f, hc = 0.f;
+  const float* __restrict__ px = bd.px;
+  if (PROJ) {
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int Xe = x0 - 2 + col + e, Ye = y0 - 2 + R;
+      const int Xc = Xe < 1 ? 1 : (Xe > g.nx - 2 ? g.nx - 2 : Xe), Yc = Ye < 1 ? 1 : (Ye > g.ny - 2 ? g.ny - 2 : Ye);
+      ho[e] = (unsigned)Xc + (unsigned)Yc * sy;
+      hd[e] = hcmp == 0 ? (Xe <= 1 || Xe >= g.nx - 1) : (hcmp == 1 ? (Ye <= 1 || Ye >= g.ny - 1) : false);
+    }
+    hnb = hcmp == 0 ? 1u : (hcmp == 1 ? sy : sz);
+    hU = hcmp == 0 ? bd.bcU[0] : (hcmp == 1 ? bd.bcU[1] : bd.bcU[2]);
+    hc = hcmp == 0 ? bd.cl_c[0] : (hcmp == 1 ? bd.cl_c[1] : bd.cl_c[2]);
+  }
+  // planes outside the local array (k = −1 below the first plane, nz above the last) are never used either: clamp.  PROJ: the ghost planes 0 and nz−1
+  // take the tangential components of planes 1 and nz−2 (BC!), so every load goes to an interior plane
   auto load_plane = [&](int kk) -> Stage {
-    const unsigned ko = (unsigned)(kk < 0 ? 0 : (kk > g.nz - 1 ? g.nz - 1 : kk)) * sz;
+    const int kc = PROJ ? (kk < 1 ? 1 : (kk > g.nz - 2 ? g.nz - 2 : kk)) : (kk < 0 ? 0 : (kk > g.nz - 1 ? g.nz - 1 : kk));
+    const unsigned ko = (unsigned)kc * sz;
     Stage st;
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) st.c[cc] = cf_ldg2(u, (unsigned)cc * cs + ko + pc.off);
-    st.h = cf_ldg2(u, hbase + ko);
+    if (PROJ) { st.h.x = u[(unsigned)hcmp * cs + ko + ho[0]]; st.h.y = u[(unsigned)hcmp * cs + ko + ho[1]]; }
+    else st.h = cf_ldg2(u, hbase + ko);
     return st;
+  };
+  // x at the cells the projection of one plane reads: the pair, its lower x / y / z neighbours, and the same for the two halo elements
+  struct XStage { float2 xc, xy, xk; float xm; float xh[2], xn[2]; };
+  auto load_x = [&](int kk) -> XStage {
+    const int kc = kk < 1 ? 1 : (kk > g.nz - 2 ? g.nz - 2 : kk);
+    const unsigned ko = (unsigned)kc * sz;
+    XStage X;
+    X.xc = cf_ldg2(px, ko + pc.off); X.xm = px[ko + pc.off - 1u]; X.xy = cf_ldg2(px, ko + pc.off - sy); X.xk = cf_ldg2(px, ko - sz + pc.off);
+#pragma unroll
+    for (int e = 0; e < 2; e++) { X.xh[e] = px[ko + ho[e]]; X.xn[e] = px[ko + ho[e] - hnb]; }
+    return X;
+  };
+  const bool dxc0 = (x == 1), dyc = (y == 1);      // the pair's first cell lies on the lower x wall face / the row on the lower y wall face
+  auto project = [&](Stage& st, const XStage& X, int kk) {
+    const bool zd = kk <= 1 || kk >= g.nz - 1;     // the z component is U on these planes
+    const float c0 = bd.cl_c[0], c1 = bd.cl_c[1], c2 = bd.cl_c[2];
+    const float p0x = st.c[0].x - c0 * (X.xc.x - X.xm), p0y = st.c[0].y - c0 * (X.xc.y - X.xc.x);
+    const float p1x = st.c[1].x - c1 * (X.xc.x - X.xy.x), p1y = st.c[1].y - c1 * (X.xc.y - X.xy.y);
+    const float p2x = st.c[2].x - c2 * (X.xc.x - X.xk.x), p2y = st.c[2].y - c2 * (X.xc.y - X.xk.y);
+    st.c[0] = make_float2(dxc0 ? bd.bcU[0] : p0x, p0y);
+    st.c[1] = make_float2(dyc ? bd.bcU[1] : p1x, dyc ? bd.bcU[1] : p1y);
+    st.c[2] = make_float2(zd ? bd.bcU[2] : p2x, zd ? bd.bcU[2] : p2y);
+    const float h0 = st.h.x - hc * (X.xh[0] - X.xn[0]), h1 = st.h.y - hc * (X.xh[1] - X.xn[1]);
+    const bool hz = hcmp == 2 && zd;
+    st.h = make_float2((hd[0] || hz) ? hU : h0, (hd[1] || hz) ? hU : h1);
   };
   auto slot_of = [&](int kk) -> float* { return lds + ((unsigned)(kk + 3) % 3u) * CF_SLOT; };
   auto write_plane = [&](int kk, const Stage& st) {
     float* sl = slot_of(kk);
 #pragma unroll
     for (int cc = 0; cc < 3; cc++) *reinterpret_cast<float2*>(sl + cc * CF_P + my) = FULL ? st.c[cc] : cf_pair_fix(st.c[cc], pc.mode);
-    *reinterpret_cast<float2*>(sl + hl) = cf_pair_fix(st.h, ph.mode);
+    *reinterpret_cast<float2*>(sl + hl) = PROJ ? st.h : cf_pair_fix(st.h, ph.mode);
   };
   // wall flags of the x and y faces (0-based cell index 1 = first interior cell, n−1 = upper ghost)
   const bool wlx = (x == 1);
@@ -170,17 +220,23 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
       }
     }
   };
-  Stage S;
+  Stage S; XStage XS;
   // ---- prologue: planes ks−1, ks, ks+1 → LDS; plane ks−2 only at the own cells; plane ks+2 in flight.  Priming = the z-face fluxes of the first plane's lower faces
   {
     float2 m2[3];
-    {
+    if (PROJ) { Stage sm = load_plane(ks - 2); const XStage xm = load_x(ks - 2); project(sm, xm, ks - 2); for (int cc = 0; cc < 3; cc++) m2[cc] = sm.c[cc]; }
+    else {
       const unsigned ko = (unsigned)(ks - 2 < 0 ? 0 : ks - 2) * sz;
 #pragma unroll
       for (int cc = 0; cc < 3; cc++) { m2[cc] = cf_ldg2(u, (unsigned)cc * cs + ko + pc.off); if (!FULL) m2[cc] = cf_pair_fix(m2[cc], pc.mode); }
     }
-    const Stage s0 = load_plane(ks - 1), s1 = load_plane(ks), s2 = load_plane(ks + 1);
+    Stage s0 = load_plane(ks - 1), s1 = load_plane(ks), s2 = load_plane(ks + 1);
+    if (PROJ) {
+      const XStage x0s = load_x(ks - 1), x1s = load_x(ks), x2s = load_x(ks + 1);
+      project(s0, x0s, ks - 1); project(s1, x1s, ks); project(s2, x2s, ks + 1);
+    }
     S = load_plane(ks + 2);
+    if (PROJ) XS = load_x(ks + 2);
     write_plane(ks - 1, s0); write_plane(ks, s1); write_plane(ks + 1, s2);
     float2 C1[3], Zp1[3], Zp2[3];
 #pragma unroll
@@ -222,6 +278,7 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
     constexpr int WALLS = decltype(wtag)::value;
     for (int k = ks; k < ke; k++) {
       // ---- stage: plane k+2 (loaded during the previous iteration) → LDS; its centres are this plane's f[I+2δz]; issue plane k+3
+      if (PROJ) project(S, XS, k + 2);
       float2 Zp2[3];
 #pragma unroll
       for (int cc = 0; cc < 3; cc++) Zp2[cc] = FULL ? S.c[cc] : cf_pair_fix(S.c[cc], pc.mode);
@@ -229,10 +286,6 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
       S = load_plane(k + 3);
       const unsigned ko = (unsigned)k * sz;
       float2 u0v[3];
-      if (!U0ADV) {
-#pragma unroll
-        for (int a = 0; a < 3; a++) { u0v[a] = cf_ldg2(bd.u0, (unsigned)a * cs + ko + pc.off); if (!FULL) u0v[a] = cf_pair_fix(u0v[a], pc.mode); }
-      }
       if (k > ks) store_plane(wtag, k - 1);
       const float* S0 = slot_of(k);
       const float* P0 = S0 + my;
@@ -290,20 +343,35 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
         gprev = ub0;
         FB[gout] = cf_flux<SCH, WALLS>(U, fa, fb, fc, fd, false, gwu, nu);
       }
-      // ---- b = z: upper face k+1 evaluated now
-      // (the face k+1 lies on a z wall on two planes of the whole domain: block-uniform branch, the common side carries no wall forms)
+      // ---- b = z: upper face k+1 (it lies on a z wall on two planes of the whole domain: block-uniform branch, the common side carries no wall forms).
+      // (Evaluating it after the barrier instead, behind the reads of the neighbours' fluxes, costs registers: +8 % on the kernel, profiles/r03_experiments.md §12.)
       float Pz[3][2];
       const int Kg = g.gk + k;
-      if (Kg + 1 == 1 || Kg + 1 == g.gnz - 1) zfaces(std::integral_constant<int, 1>{}, k, Zm1, C1, Zp1, Zp2, Pp, Pz);
+      const bool zwall = (Kg + 1 == 1 || Kg + 1 == g.gnz - 1);
+      if (zwall) zfaces(std::integral_constant<int, 1>{}, k, Zm1, C1, Zp1, Zp2, Pp, Pz);
       else zfaces(std::integral_constant<int, 0>{}, k, Zm1, C1, Zp1, Zp2, Pp, Pz);
+      // u⁰ (used after the barrier) and, with PROJ, the pressure values of plane k+3 are requested here, behind the flux arithmetic: their registers are
+      // not live across it (8 -> 2 spilled registers in the corrector, conv_diff! 2.21 -> 2.12 ms per step) and the barrier wait covers most of their latency
+      if (!U0ADV) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { u0v[a] = cf_ldg2(bd.u0, (unsigned)a * cs + ko + pc.off); if (!FULL) u0v[a] = cf_pair_fix(u0v[a], pc.mode); }
+      }
+      if (PROJ) XS = load_x(k + 3);
       __syncthreads();     // fluxes of this plane and plane k+2 are visible; nobody still reads the ring slot / flux buffer the next iteration overwrites
+      float2 PuA[3]; float PxE[3];
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        PuA[a] = cf_lds2(FB + a * CF_FYC + (ly + 1) * CF_CX + 2 * lx);
+        PxE[a] = 0.f;
+        if (lx == CF_TX - 1) PxE[a] = FB[CF_FY + a * CF_CY + ly];
+      }
       // ---- upper faces from the neighbours, accumulation in the reference's order, BDIM! (NoBody: μ₁ ≡ 0, V ≡ 0) with scale_u! folded   src/Flow.jl:176-180
       const float mz = wl::wl_cl_coef(Kg + 1, N[2], bd.cl_c[2]);      // block-uniform
 #pragma unroll
       for (int a = 0; a < 3; a++) {
         float Px2 = cf_next_lane(Px0[a]);
-        if (lx == CF_TX - 1) Px2 = FB[CF_FY + a * CF_CY + ly];
-        const float2 Pu = cf_lds2(FB + a * CF_FYC + (ly + 1) * CF_CX + 2 * lx);
+        if (lx == CF_TX - 1) Px2 = PxE[a];
+        const float2 Pu = PuA[a];
         float t0 = a0[a], t1 = a1[a];
         t0 = t0 - Pu.x;
         t1 = t1 - Px2; t1 = t1 + Pl1[a]; t1 = t1 - Pu.y;
@@ -336,6 +404,10 @@ namespace wl {
 void conv_flux_enable(int on) { g_convf_on = on; }
 bool conv_flux_on() { return g_convf_on != 0; }
 // conv_diff!(·,u_adv) + BDIM!(NoBody, μ₀ evaluated: bd.cl_on) → u_out on the owned interior planes [ka,kb) (f is not materialised); geometry checked by conv_tile_ok
+// the geometry the fused projection (PROJ) needs on top of conv_tile_ok: whole tiles, the whole single domain
+bool conv_proj_ok(const GridX& g, unsigned per) {
+  return g_convf_on && g.D == 3 && g.nz == g.gnz && g.k0 == 1 && g.k1 == g.nz - 1 && g.nz >= 6 && (g.nx - 2) % CF_CX == 0 && (g.ny - 2) % CF_CY == 0 && conv_tile_ok(g, per, g.k1 - g.k0);
+}
 int conv_flux(const float* u_adv, const GridX& g, float nu, int scheme, int ka, int kb, int zc, const void* bdp, hipStream_t s) {
   const BdimArgs bd = *(const BdimArgs*)bdp;
   const int ntiles = ((g.nx - 2 + CF_CX - 1) / CF_CX) * ((g.ny - 2 + CF_CY - 1) / CF_CY);
@@ -347,9 +419,10 @@ int conv_flux(const float* u_adv, const GridX& g, float nu, int scheme, int ka, 
   const bool u0adv = bd.u0 == u_adv;
   // predictor: u⁰ is the advecting field, pre = 0, post = 1; corrector: pre = 1, post = 1/2; anything else takes the run-time form
   const int mode = (u0adv && bd.pre == 0.f && !bd.scale_after) ? 1 : ((!u0adv && bd.pre != 0.f && bd.scale_after) ? 2 : 0);
-#define WL_CF(SCHV, FULLV, ADV, MD) hipLaunchKernelGGL((k_conv_flux<SCHV, FULLV, ADV, MD>), grid, dim3(CF_N), 0, s, g, u_adv, nu, ka, kb, zc, bd)
-#define WL_CF1(SCHV, FULLV) do { if (mode == 1) WL_CF(SCHV, FULLV, 1, 1); else if (mode == 2) WL_CF(SCHV, FULLV, 0, 2); else if (u0adv) WL_CF(SCHV, FULLV, 1, 0); else WL_CF(SCHV, FULLV, 0, 0); } while (0)
-#define WL_CF2(SCHV) do { if (full) WL_CF1(SCHV, 1); else WL_CF1(SCHV, 0); } while (0)
+  if (bd.px && !(full && mode == 2 && g.nz == g.gnz && ka == 1 && kb == g.nz - 1)) { wl_set_error("conv_flux: the fused projection needs whole tiles, the corrector's BDIM! form and the whole single domain"); return WL_EINVAL; }
+#define WL_CF(SCHV, FULLV, ADV, MD, PJ) hipLaunchKernelGGL((k_conv_flux<SCHV, FULLV, ADV, MD, PJ>), grid, dim3(CF_N), 0, s, g, u_adv, nu, ka, kb, zc, bd)
+#define WL_CF1(SCHV, FULLV) do { if (mode == 1) WL_CF(SCHV, FULLV, 1, 1, 0); else if (mode == 2) WL_CF(SCHV, FULLV, 0, 2, 0); else if (u0adv) WL_CF(SCHV, FULLV, 1, 0, 0); else WL_CF(SCHV, FULLV, 0, 0, 0); } while (0)
+#define WL_CF2(SCHV) do { if (bd.px) WL_CF(SCHV, 1, 0, 2, 1); else if (full) WL_CF1(SCHV, 1); else WL_CF1(SCHV, 0); } while (0)
   switch (scheme) {
     case WL_QUICK: WL_CF2(WL_QUICK); break;
     case WL_VANLEER: WL_CF2(WL_VANLEER); break;

@@ -29,6 +29,13 @@ __global__ void k_scale(float* __restrict__ a, float s, size_t n) {
 __global__ void k_divs(float* __restrict__ a, float s, size_t n) {
   for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) a[q] = a[q] / s;
 }
+// out = in / s (out ≠ in): the p = x/Δt half of mom_project!'s tail when the velocity half is evaluated by the corrector's loader (wl_convf.hip, PROJ)
+__global__ void k_divs_to4(float4* __restrict__ out, const float4* __restrict__ in, float s, size_t n4) {
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n4; q += (size_t)gridDim.x * WL_BLOCK) { const float4 v = in[q]; out[q] = make_float4(v.x / s, v.y / s, v.z / s, v.w / s); }
+}
+__global__ void k_divs_to(float* __restrict__ out, const float* __restrict__ in, float s, size_t n) {
+  for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) out[q] = in[q] / s;
+}
 __global__ void k_red_sum(const float* __restrict__ a, size_t n, double* __restrict__ part) {
   double acc = 0.0;
   for (size_t q = (size_t)blockIdx.x * WL_BLOCK + threadIdx.x; q < n; q += (size_t)gridDim.x * WL_BLOCK) acc += (double)a[q];
@@ -569,6 +576,11 @@ int fill(float* a, float v, size_t n, hipStream_t s) {
   hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, a, v, n); WL_LAUNCH_CHECK(); return 0;
 }
 int scale(float* a, float sc, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_scale, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, a, sc, n); WL_LAUNCH_CHECK(); return 0; }
+int div_scalar_to(float* out, const float* in, float sc, size_t n, hipStream_t s) {
+  if (n % 4 == 0 && (((size_t)out | (size_t)in) & 15) == 0) hipLaunchKernelGGL(k_divs_to4, dim3(grid1d(n / 4)), dim3(WL_BLOCK), 0, s, (float4*)out, (const float4*)in, sc, n / 4);
+  else hipLaunchKernelGGL(k_divs_to, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, out, in, sc, n);
+  WL_LAUNCH_CHECK(); return 0;
+}
 int div_scalar(float* a, float sc, size_t n, hipStream_t s) { hipLaunchKernelGGL(k_divs, dim3(grid1d(n)), dim3(WL_BLOCK), 0, s, a, sc, n); WL_LAUNCH_CHECK(); return 0; }
 int sum_dev(const float* a, size_t n, const RedWs& ws, int slot, hipStream_t s) {
   const unsigned nb = grid1d(n);
@@ -689,6 +701,10 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
     const bool foldok = fold && fold->on && SCH != WL_VANLEER && g.nz == g.gnz && own_a == g.k0 && own_b == g.k1 && g.nx >= 6 && g.ny >= 6 && g.nz >= 6;
     bt.bc_on = foldok ? 1 : 0;
     if (foldok) for (int c = 0; c < 3; c++) bt.bcU[c] = fold->U[c];
+    if (fold && fold->proj_x) {   // mom_project!'s deferred tail: the kernel reads u through u −= L∇x and BC!(u,U) (wl_convf.hip, PROJ; the caller checked conv_proj_ok)
+      bt.px = fold->proj_x; for (int c = 0; c < 3; c++) bt.bcU[c] = fold->U[c];
+      fold->proj_done = 1;
+    }
     WL_TRY(wl::conv_tile(u, g, nu, SCH, own_a, own_b, &bt, s));
     if (foldok) WL_TRY(wl::bc_zplanes(bt.uout, g, fold->U[2], s));
     if (fold) fold->on = foldok ? 1 : 0;

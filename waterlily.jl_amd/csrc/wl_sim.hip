@@ -338,9 +338,25 @@ struct wl_sim {
     }
     WL_TRY(sync_u(s));
     BcFold fr = fold_req(2);
+    fr.proj_x = proj_pending;
     WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), 1 << 30, true, &fr));
+    if (proj_pending && !fr.proj_done) { wl_set_error("mom_step!: the corrector did not take the deferred projection"); return WL_EINVAL; }
+    proj_pending = nullptr;
     bc_folded = fr.on != 0;
     return 0;
+  }
+  // mom_project!'s first tail deferred into the corrector's conv_diff! (wl_convf.hip, PROJ): the projected predictor velocity has exactly one reader — the
+  // corrector — so inside mom_step! the tail's u −= L∇x and the BC! after it are evaluated by that kernel's loader and the field is never written back
+  // (−24 B/cell, one launch); p = x/Δt keeps its own small launch.  Only where the loader's closed form is the whole story (fold_ok: single domain, tuple U,
+  // no periodic direction, no convective exit) and the corrector is the fused NoBody launch on whole tiles.
+  // OPT-IN (option "tailfuse"): bit-identical, but at 512³ the loader's extra loads cost the corrector what the tail launch took (corrector 1.19 -> 1.83 ms
+  // + 0.22 ms for p against 0.88 ms for the tail: the kernel sits at the 128-register budget of its two workgroups per CU, the x operands spill, and a
+  // spill reload's in-order vmcnt wait drains the plane prefetch) — profiles/r03_experiments.md §13.
+  bool use_tailfuse = false;
+  const float* proj_pending = nullptr;
+  bool tailfuse_ok() const {
+    return use_tailfuse && fold_ok(3) && us && !d.has_body && !forcing && !store_f && !use_convz && !u_pending && mg->lv[0].cl.on && !mg->lv[0].part &&
+           wl::conv_proj_ok(G, d.perdir_mask);
   }
   bool use_convz = false;    // z-marching conv_diff! (each flux once): bit-identical but measured 6 % SLOWER than the gather kernel at 512³ (opt-in)
   int conv_only(const float* uadv, hipStream_t s) {     // conv_diff!(f,uadv,σ) without BDIM!
@@ -434,13 +450,14 @@ struct wl_sim {
   int itmx = 32;             // solver!'s iteration cap (src/MultiLevelPoisson.jl:108); the multi-GPU rehearsal (tools/slab_rank_bench.py) lowers it to the 1 V-cycle the real run takes
   bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
   bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
+  long n_tailfuse = 0;       // projections whose velocity update ran inside the corrector's conv_diff!
   long n_resjac = 0, n_resjac_redo = 0;   // how often the fused head stood / had to be redone because the mean shift was due
   int resjac_redo_run = 0;                // consecutive redos: after WL_RESJAC_BACKOFF of them the fused head is switched off for this handle
   bool resjac_backoff = false;            // (a flow whose residual needs the mean shift on every solve would pay launch + sync + two-kernel path each time); re-armed by update!
   int p_shell = -1;          // ghost shell of p / the spare pressure array: -1 unknown (check before the next fused head), 0 all +0, 1 something else, 2 caller-owned p (never assumed)
   bool use_fuse_cfl = true;  // the corrector's projection tail also produces CFL's σ and max(σ)
   bool cfl_done = false;
-  int project(float w, hipStream_t s, bool with_cfl = false) {                           // mom_project! :223-232
+  int project(float w, hipStream_t s, bool with_cfl = false, bool defer_tail = false) {    // mom_project! :223-232 (defer_tail: inside mom_step!, the corrector follows)
     const float dtl = w * dt.back();
     cfl_done = false;
     WL_TRY(sync_u(s));                                                                     // div(u) reads the halo planes
@@ -489,6 +506,13 @@ struct wl_sim {
         WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
         std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
       } else if (split) WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s));
+      else if (defer_tail && tailfuse_ok()) {   // p = x/Δt now; u −= L∇x and BC! when the corrector reads u (the scaled x stays untouched in the spare pressure array until then)
+        WL_TRY(wl::div_scalar_to(ps, p, dtl, (size_t)G.cs, s));
+        proj_pending = p;
+        std::swap(p, ps); l0.x = p;
+        n_tailfuse++;
+        return 0;
+      }
       else { const BcFold fr = fold_req(1); WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s, &fr)); bc_folded = fr.on != 0; }
       std::swap(p, ps); l0.x = p;
       return bc_u(s);
@@ -513,7 +537,7 @@ struct wl_sim {
     if (swap_ok) { std::swap(u, u0); if (d.exitBC) WL_TRY(copy_exit_face(u, u0, s)); }   // (an exchange still in flight belongs to the array that is now u⁰ — the predictor's advecting field)
     else { WL_TRY(sync_u(s)); WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s)); }   // u⁰ .= u
     WL_TRY(predict(s));
-    WL_TRY(project(1.f, s));
+    WL_TRY(project(1.f, s, false, true));
     WL_TRY(correct(s));
     WL_TRY(project(0.5f, s, true));
     return cfl(s);
@@ -751,6 +775,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "tailfuse") { s->use_tailfuse = value != 0; return 0; }                             // mom_step!: the first projection's u −= L∇x + BC! inside the corrector's conv_diff! (default 0: no gain measured)
   if (n == "convf") { wl::conv_flux_enable(value != 0); return 0; }                            // 1: tiled conv_diff! evaluates every flux once (default), 0: k_conv_tile
   if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
   if (n == "pair") { wl::gsrb_pair_enable(value); return 0; }
@@ -774,6 +799,7 @@ int wl_sim_counter(wl_sim* s, const char* name, long* out) {
   if (n == "resjac") { *out = s->n_resjac; return 0; }
   if (n == "resjac_redo") { *out = s->n_resjac_redo; return 0; }
   if (n == "resjac_backoff") { *out = s->resjac_backoff ? 1 : 0; return 0; }
+  if (n == "tailfuse") { *out = s->n_tailfuse; return 0; }
   if (n == "xdefer") { *out = s->mg->last_xdefer; return 0; }
   wl_set_error("unknown counter " + n); return WL_EINVAL;
 }

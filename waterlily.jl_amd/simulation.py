@@ -231,6 +231,12 @@ class FusedSimulation:
         """implementation switches: "convz", "fused_smoother" (1 = default fast path, 0 = one kernel per pass)"""
         check(lib().wl_sim_set_option(self._h, name.encode(), int(value)))
 
+    def counter(self, name):
+        """path counters of the handle (include/wlhip_bench.h wl_sim_counter): "resjac", "resjac_redo", "resjac_backoff", "xdefer", "tailfuse" """
+        v = C.c_long(0)
+        check(lib().wl_sim_counter(self._h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     @property
     def dt(self):
         out = (C.c_float * 1000000)()
