@@ -343,6 +343,18 @@ int main(int argc, char** argv) {
       run_tile<MIX_B, 64, 32, 1024, 1, 0>(10); run_tile<MIX_B, 64, 32, 1024, 1, 0>(32); run_tile<MIX_B, 256, 4, 256, 1, 0>(16);
       run_tile<MIX_A, 64, 32, 1024, 1, 0>(10); run_tile<MIX_A, 64, 32, 1024, 1, 0>(32); run_tile<MIX_P, 64, 32, 1024, 1, 0>(10);
     }
+    if (*p == 'G') {   // geometry study on ONE set of allocations (same placement state throughout; run with argv[2] = 576 so that the arrays hold every case):
+                       // row pitch and the column of the first interior cell — (514,1) is the reference's layout, (514,2) what modes S/T use, the others padded rows
+      const int maxng = NG;
+      static const int geo[][2] = {{514, 1}, {514, 2}, {528, 16}, {576, 64}, {520, 8}, {544, 32}, {512, 0}, {514, 1}};
+      for (int rep = 0; rep < 2; rep++) for (auto& gq : geo) {
+        if (gq[0] > maxng) continue;
+        NG = gq[0]; OI = gq[1]; PSZ = (size_t)NG * 514;
+        printf("## pitch %d floats (%d B), first interior column %d (byte %d of its row), plane %zu B\n", NG, NG * 4, OI, OI * 4, PSZ * 4);
+        run_tile<MIX_B, 64, 32, 1024, 1, 0>(10); run_tile<MIX_A, 64, 32, 1024, 1, 0>(10); run_tile<MIX_P, 64, 32, 1024, 1, 0>(10); run_tile<MIX_R, 64, 16, 512, 1, 0>(8);
+      }
+      NG = maxng;
+    }
     if (*p == 'L') { run_locality<MIX_B>(); run_locality<MIX_R>(); run_locality<MIX_C>(); }
     if (*p == 'P') {
       run_elems<MIX_P>();
