@@ -14,7 +14,8 @@ extern "C" int wl_init(int);
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 #define WT(x) do { int r_ = (x); if (r_) { printf("library error %d at line %d: %s\n", r_, __LINE__, wl_last_error()); return 1; } } while (0)
 static const char* wl_last_error() { return "(see wl_last_error_string)"; }
-int main() {
+int main(int argc, char** argv) {
+  const bool only_head = argc > 1 && argv[1][0] == 'h';     // 'h': the fused head only (64-cell-core experiment: link against libwlhip_rj34.so, WL_RJ_X34=1)
   if (wl_init(0)) { printf("wl_init failed\n"); return 1; }
   const int N = 512, NG = N + 2, PITCH = 544;
   const size_t maxcs = (size_t)PITCH * NG * NG + 4096;
@@ -52,9 +53,12 @@ int main() {
     float *U = u + off, *U0 = u0 + off, *UO = uo + off, *P = p + off, *X2 = x2 + off, *R = r + off, *R2 = r2 + off, *EM = em + off, *EPS = eps + off;
     BdimArgs bp{U, nullptr, UO, 0.1f, 0.f, 1.f, 0, 1, {1.f, 1.f, 1.f}};                 // predictor: u⁰ is the advecting field, pre = 0, post = 1
     BdimArgs bc{U0, nullptr, UO, 0.1f, 1.f, 0.5f, 1, 1, {1.f, 1.f, 1.f}};               // corrector
+    if (!only_head) {
     if (timeit("conv_diff!+BDIM! predictor (k_conv_flux)", [&] { return wl::conv_tile(U, g, 0.01f, WL_QUICK, g.k0, g.k1, &bp, 0); })) return 1;
     if (timeit("conv_diff!+BDIM! corrector (k_conv_flux)", [&] { return wl::conv_tile(U, g, 0.01f, WL_QUICK, g.k0, g.k1, &bc, 0); })) return 1;
+    }
     if (timeit("fused projection head (k_resjac)", [&] { return wl::resjac(X2, R, P, U, g, 0.3f, 1.f, cl, ws, 0, 0, 0, false); })) return 1;
+    if (only_head) continue;
     if (timeit("smoother kernel A (k_gsrb2_A)", [&] { return wl::gsrb_fused_A(EM, R, nullptr, g, cl, 0); })) return 1;
     if (timeit("smoother kernel B (k_gsrb2_B)", [&] { return wl::gsrb_fused_B(EPS, R2, X2, EM, R, nullptr, g, 1.f, nullptr, 0, 0, cl, 0); })) return 1;
   }
