@@ -936,6 +936,43 @@ def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
     assert np.abs(res["flux"][1] - outo[1]).max() < 2e-5
 
 
+@pytest.mark.parametrize("dims", [(64, 32, 24), (72, 40, 16), (130, 34, 16), (128, 48, 12)])
+@pytest.mark.parametrize("uBC", [(1.0, 0.0, 0.0), (0.3, -0.2, 0.1)])
+def test_deferred_bc_is_bit_identical(w, oracle, dims, uBC):
+    """mom_step! with BC!(u,U) after the fused conv_diff!+BDIM! left to the projection (option bcdefer: the fused head and the pair tail read U on the
+    wall-normal boundary faces, the tails' folded stores rewrite every boundary location; two k_bc_vec launches fewer per step) against the step that
+    applies BC! where the reference does — u, u⁰, p on EVERY cell (ghosts, edges, corners), pois.n, Δt after three steps; with the fused head standing
+    (deferral live: 2 per step) and with the head forced onto its redo path (the deferred BC! is applied before the two-kernel head reads u)."""
+    rng = np.random.default_rng(67)
+    Ng = tuple(n + 2 for n in dims)
+    u_init = np.asfortranarray(rng.uniform(-0.4, 0.4, size=Ng + (3,)).astype(np.float32))
+    so = oracle.Simulation(dims, uBC, dims[0], U=1, nu=0.02, T=np.float32)
+    oracle.BC(u_init, uBC)
+    so.field("u")[...] = u_init
+    so.field("u0")[...] = u_init
+    res = {}
+    for mode, (defer, rj) in {"defer": (1, 1), "plain": (0, 1), "defer_redo": (1, 3)}.items():
+        sg = w.FusedSimulation(dims, uBC, dims[0], U=1, nu=0.02, u0=u_init)
+        sg.set_option("bcdefer", defer)
+        sg.set_option("convt_min", 0)
+        sg.set_option("resjac_min", 0)
+        sg.set_option("resjac", rj)
+        for _ in range(3):
+            sg.mom_step_()
+        res[mode] = (sg.field("u"), sg.field("u0"), sg.field("p"), sg.pois_n, sg.dt)
+        assert sg.counter("bcdefer") == {"defer": 6, "plain": 0, "defer_redo": 6}[mode], mode
+        sg.set_option("convt_min", 8192)
+        sg.set_option("resjac_min", 8 << 20)
+    for _ in range(3):
+        so.step(remeasure=False)
+    for mode in ("defer", "defer_redo"):
+        assert res[mode][3] == res["plain"][3] and res[mode][4] == res["plain"][4], mode
+        for q in range(3):
+            assert np.array_equal(res[mode][q], res["plain"][q]), (mode, ("u", "u0", "p")[q])
+    assert res["defer"][3] == so.pois_n
+    assert np.abs(res["defer"][0] - so.u).max() < 5e-5 and np.abs(res["defer"][2] - so.p).max() < 5e-4
+
+
 @pytest.mark.parametrize("dims", [(64, 32, 24), (128, 48, 16), (64, 16, 12), (192, 32, 9)])
 @pytest.mark.parametrize("uBC,lam", [((1.0, 0.0, 0.0), 0), ((0.3, -0.2, 0.1), 0), ((0.3, -0.2, 0.1), 2), ((1.0, 0.0, 0.0), 1)])
 def test_deferred_projection_is_bit_identical(w, oracle, dims, uBC, lam):

@@ -202,7 +202,9 @@ struct ProfScope {   // RAII: records start at construction and stop at destruct
 // BC!(u,U) for a tuple U folded into a producer's stores (wl_bcfold.hpp): request (on = 1, U) / report (on = 1 if it was applied)
 struct BcFold { int on; float U[3];
                 // in: x of a projection whose velocity update was deferred to this conv_diff! launch (wl_convf.hip, PROJ); out: 1 = the launch applied it
-                const float* proj_x = nullptr; int proj_done = 0; };
+                const float* proj_x = nullptr; int proj_done = 0;
+                // in: BC!(u_in,U) was deferred — the producer of u_in wrote the interior only (wl_sim, mom_step!): the tail reads the wall-normal boundary faces as U
+                int usub = 0; };
 
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {
@@ -292,9 +294,10 @@ void resjac_enable(int on, long min_cells);
 bool par_streams_ok(); hipStream_t par_stream(int i); int par_fork(hipStream_t s); int par_join(hipStream_t s);   // wl_capi.hip
 bool resjac_ok(const GridX& g, const ConstL& cl);
 int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s,
-           bool shell = true);   // shell = false: x's (and x_out's) ghost cells are known to be +0 — the ghost-shell scaling pass is skipped
+           bool shell = true, const float* bcU = nullptr);   // shell = false: x's (and x_out's) ghost cells are known to be +0 — the ghost-shell scaling pass is skipped
 int shell_nonzero(const float* a, const GridX& g, int* dev_flag, hipStream_t s);
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold = nullptr);
+bool project_cfl_pair_path(const GridX& g, const ConstL& cl);   // the two-cells-per-thread tail will run (the form that honours BcFold::usub)
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma = 1, const BcFold* fold = nullptr);
 int project_unscale_split(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);
 int project_cfl_split(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& near, const ConstL& far,

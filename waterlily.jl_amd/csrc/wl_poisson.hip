@@ -295,9 +295,16 @@ __global__ void __launch_bounds__(WL_BLOCK) k_project_cfl2(GridX g, float* __res
       const float lz = wl::wl_cl_coef(g.gk + k + 1, g.gnz, cl.c[2]), lzp = wl::wl_cl_coef(g.gk + k + 2, g.gnz, cl.c[2]);
       const float xl = in0 ? x[o - 1] : 0.f, xr = in1 ? x[o + 2] : 0.f;
       const float2 xym = pl_ld2(x, o - g.sy), xyp = pl_ld2(x, o + g.sy), xzm = pl_ld2(x, o - g.sz), xzp = pl_ld2(x, o + g.sz);
-      const float2 a0 = pl_ld2(uin, o), a1 = pl_ld2(uin, g.cs + o), a2 = pl_ld2(uin, 2 * g.cs + o);
+      float2 a0 = pl_ld2(uin, o), a1 = pl_ld2(uin, g.cs + o), a2 = pl_ld2(uin, 2 * g.cs + o);
       const float axr = in1 ? uin[o + 2] : 0.f;
-      const float2 a1p = pl_ld2(uin, g.cs + o + g.sy), a2p = pl_ld2(uin, 2 * g.cs + o + g.sz);
+      float2 a1p = pl_ld2(uin, g.cs + o + g.sy), a2p = pl_ld2(uin, 2 * g.cs + o + g.sz);
+      if (bc.usub) {   // BC!(u_in,U) deferred: the values BC! would have put on the wall-normal faces this stencil reads (index 1 and N−1 along the component's direction)
+        if (i0 == 0 || i0 == g.nx - 2) a0.y = bc.U[0];
+        if (j == 1) a1 = make_float2(bc.U[1], bc.U[1]);
+        if (j + 1 == g.ny - 1) a1p = make_float2(bc.U[1], bc.U[1]);
+        if (g.gk + k == 1) a2 = make_float2(bc.U[2], bc.U[2]);
+        if (g.gk + k + 1 == g.gnz - 1) a2p = make_float2(bc.U[2], bc.U[2]);
+      }
       // cell 0 (i0): same statements as k_project_cfl
       const float uxn0 = a0.x - lx0 * (xc.x - xl), uxp0 = a0.y - lx1 * (xc.y - xc.x);
       const float uyn0 = a1.x - ly * (xc.x - xym.x), uyp0 = a1p.x - lyp * (xyp.x - xc.x);
@@ -1143,6 +1150,7 @@ int project_unscale_split(float* u, const float* L, const float* x, float* pout,
   }
   WL_LAUNCH_CHECK(); return 0;
 }
+bool project_cfl_pair_path(const GridX& g, const ConstL& cl) { return (tail_pair_bits() & 2) && g.D == 3 && cl.on && (g.nx & 1) == 0 && g.k0 >= 1 && g.k1 <= g.nz - 1; }
 // projection tail + CFL's σ and max(σ) -> ws.res_f[slot_f]; u_out must not alias u_in
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma, const BcFold* fold) {
   if (uout == uin) { wl_set_error("project_cfl: output aliases input"); return WL_EINVAL; }
@@ -1150,7 +1158,8 @@ int project_cfl(float* uout, const float* uin, const float* L, const float* x, f
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
-  if ((tail_pair_bits() & 2) && g.D == 3 && cl.on && (g.nx & 1) == 0 && g.k0 >= 1 && g.k1 <= g.nz - 1) {   // two cells per thread, linear order (k_project_cfl2)
+  if (fold && fold->usub && !(bc.on && project_cfl_pair_path(g, cl))) { wl_set_error("project_cfl: deferred BC! needs the folded two-cells-per-thread tail"); return WL_EINVAL; }
+  if (project_cfl_pair_path(g, cl)) {   // two cells per thread, linear order (k_project_cfl2)
     hipLaunchKernelGGL(k_enc_init, dim3(1), dim3(WL_ENC_SLOTS), 0, s, reinterpret_cast<int*>(ws.pm));
     hipLaunchKernelGGL(k_project_cfl2, dim3(pl_grid(g, g.nz)), dim3(WL_BLOCK), 0, s, g, uout, uin, x, pout, sigma, dt, cl, kfirst, klast, ws.pm, 0, g.nz, store_sigma, bc);
     hipLaunchKernelGGL(k_fin_max_enc, dim3(1), dim3(WL_BLOCK), 0, s, reinterpret_cast<const int*>(ws.pm), ws.res_f + slot_f);

@@ -25,6 +25,7 @@ __device__ __forceinline__ void rj_st2(float* __restrict__ p, unsigned o, float2
   if (s0 && s1) *reinterpret_cast<float2*>(p + o) = v;
   else { if (s0) p[o] = v.x; if (s1) p[o + 1] = v.y; }
 }
+struct RjBc { int on; float U[3]; };     // u is read through BC!(u,U): see wl_resjac_body.inc
 int g_resjac_on = 1;
 long g_resjac_min = 6L << 20;   // cells: below this the extra host read of Σr costs more than the fusion saves (tools/rj_gate.sh: 192³ −3.5 %, 160³ even, 128³ +4 %)
 
@@ -115,7 +116,7 @@ int shell_nonzero(const float* a, const GridX& g, int* dev_flag, hipStream_t s) 
   WL_HIP(hipStreamSynchronize(s));
   return h ? 1 : 0;
 }
-int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s, bool shell) {
+int resjac(float* xout, float* rout, const float* x, const float* u, const GridX& g, float dt, float w, const ConstL& cl, const RedWs& ws, int slot_d, int slot_f, hipStream_t s, bool shell, const float* bcU) {
   if (xout == x) { wl_set_error("resjac: output aliases input"); return WL_EINVAL; }
   const int np = g.k1 - g.k0;
   // 16-row tiles (512 threads, four resident workgroups per CU): measured faster at every size (tools/rj_rows.sh: head 0.30 -> 0.275 ms/step at 256³,
@@ -147,8 +148,10 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
   const unsigned nb = (unsigned)(8 * per * nch);
   if (nb > WL_MAXPART) { wl_set_error("resjac: too many workgroups for the reduction workspace"); return WL_EINVAL; }
   if (shell) hipLaunchKernelGGL(k_scale_shell, dim3(8, (unsigned)g.nz), dim3(WL_BLOCK), 0, s, g, xout, x, dt);
-  if (r16) rj16::rj_launch(nb, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm);
-  else rj32::rj_launch(nb, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm);
+  RjBc bc{0, {0.f, 0.f, 0.f}};
+  if (bcU) { if (g.nz != g.gnz) { wl_set_error("resjac: BC! on load is for the single domain"); return WL_EINVAL; } bc.on = 1; for (int a = 0; a < 3; a++) bc.U[a] = bcU[a]; }
+  if (r16) rj16::rj_launch(nb, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm, bc);
+  else rj32::rj_launch(nb, s, g, xout, rout, x, u, dt, w, cl, zc, ws.pa, ws.pb, ws.pm, bc);
   hipLaunchKernelGGL(k_resjac_fin, dim3(1), dim3(WL_BLOCK), 0, s, (const double*)ws.pa, (const double*)ws.pb, (const float*)ws.pm, (int)nb, ws.res_d, ws.res_f, slot_d, slot_f);
   WL_LAUNCH_CHECK(); return 0;
 }

@@ -404,24 +404,50 @@ struct wl_sim {
   }
   int exit_bc(hipStream_t s);
   int copy_exit_face(float* dst, const float* src, hipStream_t s);
+  // BC!(u,U) after the fused conv_diff!+BDIM! DEFERRED inside mom_step! (option "bcdefer"): between that launch and the projection's tail — which rewrites
+  // every boundary location of u through its folded stores — the only reader of boundary locations is the projection head's ∇·u (and the second tail's
+  // flux_out), and only where a component is normal to the face, where BC! writes the constant U: the fused head and the pair tail substitute U on load
+  // (wl_resjac_body.inc, k_project_cfl2) and the two k_bc_vec launches per step (2 × 0.07 ms at 512³: strided x faces) disappear.  Every other path that
+  // would read u first (two-kernel head after a redo, unfused tails, wl_sim_phase, fields handed out) applies BC! before it does.
+  bool use_bcdefer = true, in_step = false, bc_deferred = false;
+  long n_bcdefer = 0;
+  bool head_fused_ok() const {      // the projection will start with the fused head (wl_resjac.hip) — the condition project() tests
+    const wl_mg::Level& l0 = mg->lv[0];
+    return ps && use_fuse_p && use_resjac && !resjac_backoff && (!resjac_force_redo || redo_unannounced) && !d.exitBC && !store_f && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 &&
+           wl::resjac_ok(G, l0.cl) && !comm;
+  }
+  bool bcdefer_ok(bool second) const {
+    if (!(use_bcdefer && in_step && !bc_folded && fold_ok(1) && head_fused_ok())) return false;
+    return !second || (use_fuse_cfl && us && wl::project_cfl_pair_path(G, mg->lv[0].cl));
+  }
+  int bc_u_or_defer(bool second, hipStream_t s) {
+    if (bcdefer_ok(second)) { bc_deferred = true; n_bcdefer++; return 0; }
+    return bc_u(s);
+  }
+  int flush_bc(hipStream_t s) {       // apply a deferred BC! now (somebody is about to read u's boundary locations from memory)
+    if (!bc_deferred) return 0;
+    bc_deferred = false;
+    return wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s);
+  }
   int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
     if (hybrid_ok()) {
       WL_TRY(conv_bdim_body(u0, u, 0.f, 1.f, s));
       return bc_u(s);
     }
+    bool fused_conv = false;
     if (us && !d.has_body && !forcing) {   // conv_diff!(f,u⁰) + BDIM! in one launch (u⁰ is the advecting field, u the output)
       ProfScope pc(WL_PROF_CONVDIFF, s);
       if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
         WL_TRY(sync_u(s));
         WL_TRY(wl::conv_diff_z(store_f ? f : nullptr, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
         WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
-      } else WL_TRY(conv_fused(u0, u, 0.f, 1.f, s));
+      } else { WL_TRY(conv_fused(u0, u, 0.f, 1.f, s)); fused_conv = true; }
     } else {
       { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
       if (forcing) WL_TRY(wl::accelerate(f, G, acc0, s));                                  // accelerate!(f,t₀,g,uBC)
       WL_TRY(bdim_step(0.f, 1.f, s));   // scale_u!(a,0) folded (pre=0)
     }
-    WL_TRY(bc_u(s));
+    WL_TRY(fused_conv ? bc_u_or_defer(false, s) : bc_u(s));      // (deferral implies !exitBC: fold_ok)
     if (d.exitBC) WL_TRY(exit_bc(s));
     return 0;
   }
@@ -432,15 +458,16 @@ struct wl_sim {
       return bc_u(s);
     }
     if (us && !d.has_body && !forcing) {   // the advecting field is u itself: write the new u to the spare array and swap
+      bool fused_conv = false;
       { ProfScope pc(WL_PROF_CONVDIFF, s);
         if (use_convz && wl::conv_z_ok(G, d.perdir_mask)) {
           WL_TRY(sync_u(s));
           WL_TRY(wl::conv_diff_z(store_f ? f : nullptr, u, u0, mu0, us, G, d.nu, d.scheme, dt.back(), 1.f, 0.5f, s));
           WL_TRY(wl::conv_q1(sigma, u, G, d.nu, d.perdir_mask, d.scheme, s));
-        } else WL_TRY(conv_fused(u, us, 1.f, 0.5f, s)); }
+        } else { WL_TRY(conv_fused(u, us, 1.f, 0.5f, s)); fused_conv = true; } }
       std::swap(u, us);
       if (d.exitBC) WL_TRY(copy_exit_face(u, us, s));   // BC!(…,saveexit) keeps the predictor's exit face
-      return bc_u(s);
+      return fused_conv ? bc_u_or_defer(true, s) : bc_u(s);
     }
     { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u, s)); }
     if (forcing) WL_TRY(wl::accelerate(f, G, acc1, s));                                    // accelerate!(f,t₁,g,uBC)
@@ -450,6 +477,7 @@ struct wl_sim {
   int itmx = 32;             // solver!'s iteration cap (src/MultiLevelPoisson.jl:108); the multi-GPU rehearsal (tools/slab_rank_bench.py) lowers it to the 1 V-cycle the real run takes
   bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
   bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
+  bool redo_unannounced = false;    // test hook: … and do not let the BC! deferral know in advance (as with a real shift)
   long n_tailfuse = 0;       // projections whose velocity update ran inside the corrector's conv_diff!
   long n_resjac = 0, n_resjac_redo = 0;   // how often the fused head stood / had to be redone because the mean shift was due
   int resjac_redo_run = 0;                // consecutive redos: after WL_RESJAC_BACKOFF of them the fused head is switched off for this handle
@@ -461,6 +489,7 @@ struct wl_sim {
     const float dtl = w * dt.back();
     cfl_done = false;
     WL_TRY(sync_u(s));                                                                     // div(u) reads the halo planes
+    if (bc_deferred && !head_fused_ok()) WL_TRY(flush_bc(s));                              // (cannot happen: the deferral tested the same condition — kept as the invariant's guard)
     if (ps && use_fuse_p && !(comm && d.perdir_mask)) {   // (z-slabs: p's ghost planes are current — exchanged at the end of the last solve, scaled with the rest)
       WL_TRY(wl::bc_per_scalar(p, G, d.perdir_mask, s));                                   // residual!: perBC!(x) :93 (copies commute with the scaling)
       // head: z=div(u); x.*=dt; residual! in one pass — the scaled pressure goes to the spare array, which becomes p
@@ -474,7 +503,7 @@ struct wl_sim {
           // p's and the spare's ghost cells are +0 unless someone wrote them from outside (checked once after a pointer to p was handed out): no shell pass then
           if (comm) p_shell = 1;   // (a slab's ghost planes hold the neighbours' pressure: always scaled with the rest)
           if (p_shell < 0) p_shell = (wl::shell_nonzero(p, G, (int*)(mg->ws.res_f + 7), s) || wl::shell_nonzero(ps, G, (int*)(mg->ws.res_f + 7), s)) ? 1 : 0;
-          WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s, p_shell != 0)); }
+          WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s, p_shell != 0, bc_deferred ? d.uBC : nullptr)); }
         WL_TRY(wl::combine_results(comm, mg->ws, s));            // z-slabs: Σr, L₁ (sums) and L∞ (max) over the ranks — every rank takes the same branch below
         double hd2[2]; WL_TRY(wl::read_results(mg->ws, hd2, 2, &pre_rinf, 1, s));
         const double sr = hd2[0]; pre_r1 = hd2[1];
@@ -489,6 +518,7 @@ struct wl_sim {
         }
       }
       if (!head_done) {
+        WL_TRY(flush_bc(s));      // the two-kernel head reads u's boundary faces from memory
         ProfScope pr(WL_PROF_RESIDUAL, s);
         if (l0.part && mg->use_zsplit && !comm) {   // a body: coefficients from the position on the plane ranges away from it (as in smooth!)
           const int m = 4, na = std::max(l0.g.k0, l0.za - m), nb = std::min(l0.g.k1, l0.zb + m + 1);
@@ -501,13 +531,20 @@ struct wl_sim {
       const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
       const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
       if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
-        if (split) WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s, store_f ? 1 : 0));
-        else { const BcFold fr = fold_req(1); WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s, store_f ? 1 : 0, &fr)); bc_folded = fr.on != 0; }
+        if (split) { WL_TRY(flush_bc(s)); WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s, store_f ? 1 : 0)); }
+        else {
+          BcFold fr = fold_req(1);
+          if (bc_deferred && !(fr.on && wl::project_cfl_pair_path(G, l0.cl))) WL_TRY(flush_bc(s));
+          fr.usub = bc_deferred ? 1 : 0;      // flux_out reads the wall-normal boundary faces of the corrector's output: U on load
+          WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s, store_f ? 1 : 0, &fr)); bc_folded = fr.on != 0;
+          bc_deferred = false;                // the folded stores wrote every boundary location of the new u
+        }
         WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
         std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
       } else if (split) WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s));
       else if (defer_tail && tailfuse_ok()) {   // p = x/Δt now; u −= L∇x and BC! when the corrector reads u (the scaled x stays untouched in the spare pressure array until then)
         WL_TRY(wl::div_scalar_to(ps, p, dtl, (size_t)G.cs, s));
+        bc_deferred = false;                  // (the corrector's loader reads this u through the projection AND BC!: nothing in memory is missing)
         proj_pending = p;
         std::swap(p, ps); l0.x = p;
         n_tailfuse++;
@@ -515,8 +552,10 @@ struct wl_sim {
       }
       else { const BcFold fr = fold_req(1); WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s, &fr)); bc_folded = fr.on != 0; }
       std::swap(p, ps); l0.x = p;
+      bc_deferred = false;      // the tails above update a cell from its own value only; whatever BC! had not been applied is applied now (folded stores or bc_u)
       return bc_u(s);
     }
+    WL_TRY(flush_bc(s));
     WL_TRY(wl::div_scale(sigma, p, u, G, dtl, s));                                       // z=div(u); x.*=dt
     WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s));
     WL_TRY(wl::project(u, mu0, p, G, s));
@@ -536,10 +575,12 @@ struct wl_sim {
     // every interior cell of u (BDIM! with pre=0) and BC! every ghost cell, so nothing of the old u survives anyway.
     if (swap_ok) { std::swap(u, u0); if (d.exitBC) WL_TRY(copy_exit_face(u, u0, s)); }   // (an exchange still in flight belongs to the array that is now u⁰ — the predictor's advecting field)
     else { WL_TRY(sync_u(s)); WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s)); }   // u⁰ .= u
+    struct InStep { bool& f; InStep(bool& b) : f(b) { f = true; } ~InStep() { f = false; } } guard(in_step);
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s, false, true));
     WL_TRY(correct(s));
     WL_TRY(project(0.5f, s, true));
+    WL_TRY(flush_bc(s));      // (nothing is pending here: every projection ends with BC! applied — guard)
     return cfl(s);
   }
 };
@@ -772,9 +813,10 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "deep_halo") { s->mg->deep_halo = value != 0; return 0; }
   if (n == "x_halo") { if (value < 1 || value > s->G.k0) { wl_set_error("x_halo: 1 .. ghost depth of the slab"); return WL_EINVAL; } s->mg->x_halo_depth = value; return 0; }   // 1: the fused head stays off on z-slabs
   if (n == "bcfold") { s->use_bcfold = value; return 0; }   // bit 0: projection tails, bit 1: tiled conv_diff!+BDIM!
-  if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2; return 0; }   // 2: always take the redo path (tests)
+  if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2 || value == 3; s->redo_unannounced = value == 3; return 0; }   // 2: always take the redo path (tests); 3: the same, unknown to the BC! deferral (tests: its flush before the two-kernel head)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "bcdefer") { s->use_bcdefer = value != 0; return 0; }                               // mom_step!: BC! after the fused conv_diff!+BDIM! left to the projection (its head reads U on the wall-normal faces, its tail rewrites the boundary); default 1
   if (n == "tailfuse") { s->use_tailfuse = value != 0; return 0; }                             // mom_step!: the first projection's u −= L∇x + BC! inside the corrector's conv_diff! (default 0: no gain measured)
   if (n == "convf") { wl::conv_flux_enable(value != 0); return 0; }                            // 1: tiled conv_diff! evaluates every flux once (default), 0: k_conv_tile
   if (n == "convt") { wl::conv_tile_enable(value != 0, value > 1 ? value : 0); return 0; }   // 0 off, 1 on, >1: on with that z-chunk
@@ -800,6 +842,7 @@ int wl_sim_counter(wl_sim* s, const char* name, long* out) {
   if (n == "resjac_redo") { *out = s->n_resjac_redo; return 0; }
   if (n == "resjac_backoff") { *out = s->resjac_backoff ? 1 : 0; return 0; }
   if (n == "tailfuse") { *out = s->n_tailfuse; return 0; }
+  if (n == "bcdefer") { *out = s->n_bcdefer; return 0; }
   if (n == "xdefer") { *out = s->mg->last_xdefer; return 0; }
   wl_set_error("unknown counter " + n); return WL_EINVAL;
 }
