@@ -327,19 +327,21 @@ struct wl_sim {
   }
   // fused conv_diff!+BDIM! (NoBody): interior planes first when the advecting field's halo is still in flight
   bool store_f = false;      // the fused paths materialise the intermediates f = u⁰+Δt·r and z = ∇·u only on request: nothing on the time-step path reads them again
-  int conv_fused(const float* uadv, float* uout, float pre, float post, hipStream_t s) {
+  // want_q1: also leave conv_diff!'s stale Φ in σ's ghost cells (quirk Q1: CFL's maximum(σ) sees them) — one small launch.  The predictor's are dead inside
+  // mom_step!: the corrector's conv_diff! overwrites every one of them before anything reads σ's ghost cells.
+  int conv_fused(const float* uadv, float* uout, float pre, float post, hipStream_t s, bool want_q1 = true) {
     const wl::ConstL& cl = mg->lv[0].cl;
     float* f = store_f ? this->f : nullptr;
     if (u_pending && G.D == 3 && G.k1 - G.k0 > 4) {
       WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k0 + 2, G.k1 - 2, false));
       WL_TRY(sync_u(s));
       WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), G.k0 + 2, false));
-      return wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k1 - 2, 1 << 30, true);
+      return wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k1 - 2, 1 << 30, want_q1);
     }
     WL_TRY(sync_u(s));
     BcFold fr = fold_req(2);
     fr.proj_x = proj_pending;
-    WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), 1 << 30, true, &fr));
+    WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), 1 << 30, want_q1, &fr));
     if (proj_pending && !fr.proj_done) { wl_set_error("mom_step!: the corrector did not take the deferred projection"); return WL_EINVAL; }
     proj_pending = nullptr;
     bc_folded = fr.on != 0;
@@ -441,7 +443,7 @@ struct wl_sim {
         WL_TRY(sync_u(s));
         WL_TRY(wl::conv_diff_z(store_f ? f : nullptr, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
         WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
-      } else { WL_TRY(conv_fused(u0, u, 0.f, 1.f, s)); fused_conv = true; }
+      } else { WL_TRY(conv_fused(u0, u, 0.f, 1.f, s, !(in_step && !store_f))); fused_conv = true; }
     } else {
       { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
       if (forcing) WL_TRY(wl::accelerate(f, G, acc0, s));                                  // accelerate!(f,t₀,g,uBC)
