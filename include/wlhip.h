@@ -200,6 +200,9 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[6 Mi cells] size gate (tests: 0)
+   "headspec"[1] the solver's first V-cycle is queued behind the fused projection head before Σr (residual!'s mean-shift test) has been read back — solver! runs at
+       least one cycle whatever the norms are; Σr returns with the first iteration's norms, and if the shift was due after all that solve is discarded (inputs untouched)
+       and the two-kernel path taken.  Single GPU.  One host round trip per solve fewer.
    "bcdefer"[1] wl_sim_mom_step: BC!(u,U) after the fused conv_diff!+BDIM! is left to the projection that follows — its fused head (and the second tail's flux_out) read U
        on the wall-normal boundary faces, its tail's folded stores rewrite every boundary location — two BC! launches fewer per step; results identical on every cell.
        Only where all of that holds (tuple U, single domain, no periodic direction / exit / body, fused head and folded tails in use); wl_sim_phase applies BC! as before.

@@ -437,6 +437,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
       for (int i = 0; i < 3; i++) if (norm_slots & (1 << i)) { a += hd[SD[i]]; m = std::fmax(m, hf[SF[i]]); }
       hd[2] = a; hf[1] = m;
     }
+    if (np == 0) first_hd0 = hd[0];
     if (!have_r1) { r1 = (float)hd[1]; log_r1.push_back(hd[1]); log_rinf.push_back(hf[0]); log_w.push_back(1.0); have_r1 = true; }
     const float rnew = (float)hd[2]; rinf = hf[1]; np++;
     log_r1.push_back((double)rnew); log_rinf.push_back((double)rinf); log_w.push_back((double)w);

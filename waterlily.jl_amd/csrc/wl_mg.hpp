@@ -31,6 +31,7 @@ struct wl_mg {
   bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
   bool shift_pending = false;
   bool deep_halo = true;     // z-slabs with >= 5 ghost planes: one r exchange (5 planes) per smooth! instead of r (2) + ϵ_mid (3) + r' (2)
+  double first_hd0 = 0.0;   // res_d[0] as the first iteration's read found it (the fused head's Σr when its check is deferred: wl_sim)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
   bool par_ranges = false;  // levels with a body: the plane ranges of the z-split on concurrent streams (wl::par_fork / par_join) — measured SLOWER (sphere 256³ 2.84 -> 3.07 ms: the fork/join events cost more than the overlap of 35–76 µs launches returns); "zsplit_par" turns it on

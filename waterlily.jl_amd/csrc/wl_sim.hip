@@ -478,6 +478,7 @@ struct wl_sim {
   }
   int itmx = 32;             // solver!'s iteration cap (src/MultiLevelPoisson.jl:108); the multi-GPU rehearsal (tools/slab_rank_bench.py) lowers it to the 1 V-cycle the real run takes
   bool use_resjac = true;    // projection head + first Jacobi! in one launch (wl_resjac.hip) where eligible
+  bool use_headspec = true;  // … and the first V-cycle queued behind it without waiting for Σr (single GPU)
   bool resjac_force_redo = false;   // test hook: behave as if the mean shift were always due (exercises the redo path)
   bool redo_unannounced = false;    // test hook: … and do not let the BC! deferral know in advance (as with a real shift)
   long n_tailfuse = 0;       // projections whose velocity update ran inside the corrector's conv_diff!
@@ -498,6 +499,7 @@ struct wl_sim {
       wl_mg::Level& l0 = mg->lv[0];
       bool head_done = false;
       double pre_r1 = 0.0; float pre_rinf = 0.f;
+      bool solved = false;      // the speculative solve behind the fused head stood
       if (use_resjac && !resjac_backoff && !d.exitBC && !store_f && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl) &&
           (!comm || (l0.dist && mg->x_halo_depth >= 2))) {   // (exitBC: the convective exit leaves a net flux imbalance to the solver's tolerance — the shift is usually due; z-slab: p's ghost planes are current two deep)
         // head + the V-cycle's first Jacobi!(fine) in one launch, assuming residual!'s mean shift is not due (wl_resjac.hip); Σr decides
@@ -506,6 +508,23 @@ struct wl_sim {
           if (comm) p_shell = 1;   // (a slab's ghost planes hold the neighbours' pressure: always scaled with the rest)
           if (p_shell < 0) p_shell = (wl::shell_nonzero(p, G, (int*)(mg->ws.res_f + 7), s) || wl::shell_nonzero(ps, G, (int*)(mg->ws.res_f + 7), s)) ? 1 : 0;
           WL_TRY(wl::resjac(ps, l0.eps, p, u, G, dtl, 1.f, l0.cl, mg->ws, 1, 0, s, p_shell != 0, bc_deferred ? d.uBC : nullptr)); }
+        if (use_headspec && !comm && itmx >= 1) {
+          // solver! runs its V-cycle at least once whatever the initial norms are (src/MultiLevelPoisson.jl:113-123), so Σr is not needed before the first cycle is
+          // queued: the cycle is launched behind the head at once and Σr comes back with the first iteration's norms (one host round trip per solve fewer, no idle
+          // GPU while the host decides).  If the shift turns out to be due, that solve is discarded — the head's inputs are untouched — and the two-kernel path taken.
+          std::swap(p, ps); l0.x = p;
+          std::swap(l0.r, l0.eps);
+          mg->jacobi0_done = true;
+          WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s, true, nullptr, nullptr));
+          const float sm = (float)mg->first_hd0 / (float)(double)wl_ninside_global(mg->lv[0].g);
+          if (std::fabs(sm) <= 2.f * 1.1920929e-7f && !resjac_force_redo) { head_done = true; solved = true; n_resjac++; resjac_redo_run = 0; }
+          else {
+            std::swap(l0.r, l0.eps); std::swap(p, ps); l0.x = p;
+            mg->n.pop_back(); mg->jacobi0_done = false;
+            n_resjac_redo++;
+            if (!resjac_force_redo && ++resjac_redo_run >= 3) resjac_backoff = true;
+          }
+        } else {
         WL_TRY(wl::combine_results(comm, mg->ws, s));            // z-slabs: Σr, L₁ (sums) and L∞ (max) over the ranks — every rank takes the same branch below
         double hd2[2]; WL_TRY(wl::read_results(mg->ws, hd2, 2, &pre_rinf, 1, s));
         const double sr = hd2[0]; pre_r1 = hd2[1];
@@ -518,6 +537,7 @@ struct wl_sim {
           n_resjac_redo++;
           if (!resjac_force_redo && ++resjac_redo_run >= 3) resjac_backoff = true;
         }
+        }
       }
       if (!head_done) {
         WL_TRY(flush_bc(s));      // the two-kernel head reads u's boundary faces from memory
@@ -528,7 +548,7 @@ struct wl_sim {
         } else WL_TRY(wl::div_residual(store_f ? sigma : nullptr, ps, l0.r, p, u, mu0, l0.D, l0.iD, G, dtl, mg->ws, l0.cl, s));
       }
       if (!head_done) { std::swap(p, ps); l0.x = p; }
-      WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s, true, head_done ? &pre_r1 : nullptr, head_done ? &pre_rinf : nullptr));
+      if (!solved) WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s, true, head_done ? &pre_r1 : nullptr, head_done ? &pre_rinf : nullptr));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
       const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
       const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
@@ -818,6 +838,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2 || value == 3; s->redo_unannounced = value == 3; return 0; }   // 2: always take the redo path (tests); 3: the same, unknown to the BC! deferral (tests: its flush before the two-kernel head)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "headspec") { s->use_headspec = value != 0; return 0; }                             // the first V-cycle is queued behind the fused head before Σr is known (default 1)
   if (n == "bcdefer") { s->use_bcdefer = value != 0; return 0; }                               // mom_step!: BC! after the fused conv_diff!+BDIM! left to the projection (its head reads U on the wall-normal faces, its tail rewrites the boundary); default 1
   if (n == "tailfuse") { s->use_tailfuse = value != 0; return 0; }                             // mom_step!: the first projection's u −= L∇x + BC! inside the corrector's conv_diff! (default 0: no gain measured)
   if (n == "convf") { wl::conv_flux_enable(value != 0); return 0; }                            // 1: tiled conv_diff! evaluates every flux once (default), 0: k_conv_tile
