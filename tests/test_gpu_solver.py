@@ -1024,10 +1024,11 @@ def test_fused_projection_head_is_bit_identical(w, oracle, dims):
     so.field("u")[...] = u_init
     so.field("u0")[...] = u_init
     res = {}
-    for mode in (1, 0, 2):
+    for mode in (1, 0, 2, 11, 12):      # 1: fused head (first V-cycle queued before Σr is read: headspec), 0: two kernels, 2: forced redo; 11 / 12: as 1 / 2 with headspec off
         sg = w.FusedSimulation(dims, (1.0, 0.0, 0.0), dims[0], U=1, nu=0.02, u0=u_init)
         sg.set_option("resjac_min", 0)
-        sg.set_option("resjac", mode)
+        sg.set_option("resjac", mode % 10)
+        sg.set_option("headspec", 0 if mode > 10 else 1)
         os.environ.pop("WL_RJ_CHUNK", None)
         for _ in range(3):
             sg.mom_step_()
@@ -1035,7 +1036,7 @@ def test_fused_projection_head_is_bit_identical(w, oracle, dims):
         sg.set_option("resjac_min", 8 << 20)
     for _ in range(3):
         so.step(remeasure=False)
-    for mode in (1, 2):
+    for mode in (1, 2, 11, 12):
         assert res[mode][2] == res[0][2] and res[mode][3] == res[0][3], mode
         assert np.array_equal(res[mode][0], res[0][0]) and np.array_equal(res[mode][1], res[0][1]), mode
     assert res[1][2] == so.pois_n
