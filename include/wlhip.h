@@ -200,6 +200,8 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[6 Mi cells] size gate (tests: 0)
+   "tailspec"[1] the projection tail is queued behind the smoother before the host has read that iteration's norms and gated on the device by solver!'s break test
+       (the flag the host then takes its own decision from): it runs iff the iteration was the last one.  Single GPU, the in-place tail and the pair tail with CFL.
    "headspec"[1] the solver's first V-cycle is queued behind the fused projection head before Σr (residual!'s mean-shift test) has been read back — solver! runs at
        least one cycle whatever the norms are; Σr returns with the first iteration's norms, and if the shift was due after all that solve is discarded (inputs untouched)
        and the two-kernel path taken.  Single GPU.  One host round trip per solve fewer.

@@ -29,6 +29,7 @@ int wl_placement_scores(double* out, int cap);
  * "resjac_redo" = solves where residual!'s mean shift was due after all and the head was redone on the two-kernel path,
  * "resjac_backoff" = 1 once three consecutive redos switched the fused head off for this handle (re-armed by wl_sim_update),
  * "bcdefer" = BC!(u,U) applications after conv_diff!+BDIM! that were left to the following projection (two per step when the option is live),
+ * "tailspec" = projection tails that ran from inside the solver loop, ahead of the convergence read,
  * "tailfuse" = projections whose velocity update (u −= L∇x, BC!) was evaluated by the corrector's conv_diff! loader instead of a tail launch,
  * "xdefer" = what the finest level's last smooth! decided: 1 the V-cycle's x += ω·x_c↓ was applied by smoother kernel B, 0 by kernel A, −1 none yet
  * (decides which bytes bench.py books to kernels A and B) */

@@ -936,6 +936,41 @@ def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
     assert np.abs(res["flux"][1] - outo[1]).max() < 2e-5
 
 
+@pytest.mark.parametrize("dims", [(64, 32, 24), (72, 40, 16), (128, 48, 12)])
+def test_tail_queued_ahead_of_the_convergence_read_is_bit_identical(w, oracle, dims):
+    """The projection tail queued behind the smoother BEFORE the host has read that iteration's norms, gated on the device by solver!'s break test (and, on the
+    first iteration, the fused head's mean-shift test) — option tailspec — against the tail launched after the read: u, u⁰, p on every cell, pois.n, Δt after four
+    steps from a random field (the first solves need several V-cycles: the gated tail must have done nothing on all but the last iteration), and the counter."""
+    rng = np.random.default_rng(71)
+    Ng = tuple(n + 2 for n in dims)
+    uBC = (0.3, -0.2, 0.1)
+    u_init = np.asfortranarray(rng.uniform(-0.4, 0.4, size=Ng + (3,)).astype(np.float32))
+    so = oracle.Simulation(dims, uBC, dims[0], U=1, nu=0.02, T=np.float32)
+    oracle.BC(u_init, uBC)
+    so.field("u")[...] = u_init
+    so.field("u0")[...] = u_init
+    res = {}
+    for spec in (1, 0):
+        sg = w.FusedSimulation(dims, uBC, dims[0], U=1, nu=0.02, u0=u_init)
+        sg.set_option("tailspec", spec)
+        sg.set_option("convt_min", 0)
+        sg.set_option("resjac_min", 0)
+        for _ in range(4):
+            sg.mom_step_()
+        res[spec] = (sg.field("u"), sg.field("u0"), sg.field("p"), sg.pois_n, sg.dt)
+        assert (sg.counter("tailspec") >= 4) if spec else (sg.counter("tailspec") == 0)     # (a solve whose head had to be redone, or that hit the iteration cap, launches its tail after the read)
+        sg.set_option("convt_min", 8192)
+        sg.set_option("resjac_min", 8 << 20)
+    for _ in range(4):
+        so.step(remeasure=False)
+    assert max(res[1][3]) > 1, "the case must contain solves that iterate"
+    assert res[1][3] == res[0][3] and res[1][4] == res[0][4]
+    for q in range(3):
+        assert np.array_equal(res[1][q], res[0][q]), ("u", "u0", "p")[q]
+    assert res[1][3] == so.pois_n
+    assert np.abs(res[1][0] - so.u).max() < 5e-5
+
+
 @pytest.mark.parametrize("dims", [(64, 32, 24), (72, 40, 16), (130, 34, 16), (128, 48, 12)])
 @pytest.mark.parametrize("uBC", [(1.0, 0.0, 0.0), (0.3, -0.2, 0.1)])
 def test_deferred_bc_is_bit_identical(w, oracle, dims, uBC):

@@ -423,6 +423,9 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
   int np = 0;
   log_r1.clear(); log_rinf.clear(); log_w.clear();
   if (jacobi0_done && pre_r1 && pre_rinf) { r1 = (float)*pre_r1; log_r1.push_back(*pre_r1); log_rinf.push_back((double)*pre_rinf); log_w.push_back(1.0); have_r1 = true; }
+  std::function<int(const float*)> tail; tail.swap(spec_tail);     // one-shot
+  const bool check_head = spec_check_head; spec_check_head = false;
+  tail_stood = false;
   while (np < itmx) {
     WL_TRY(vcycle(0, w, s, true));
     bool nd = false;
@@ -430,7 +433,12 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     WL_TRY(smooth(0, 4, w, s, true, &nd));                                                // fused path: norms come out of kernel B
     if (!nd) { norm_slots = 0; WL_TRY(wl::norms_dev(lv[0].r, p.x_, ws, 2, 1, s)); }       // rnew -> res_d[2], r∞ -> res_f[1]
     WL_TRY(wl::combine_results(comm, ws, s));                                             // (slot 0 becomes P·Σr: not used again)
-    WL_TRY(wl::read_results(ws, hd, 7, hf, 4, s));
+    const bool spec = (bool)tail && norm_slots == 0 && !comm;
+    if (spec) {   // the break test on the device, and the projection tail behind it: runs iff this iteration is the last one
+      WL_TRY(wl::decide_converged(ws, r1tol, rinftol, (double)wl_ninside_global(p.g), (check_head && np == 0) ? 1 : 0, 2, 1, 4, s));
+      WL_TRY(tail(ws.res_f + 4));
+    }
+    WL_TRY(wl::read_results(ws, hd, 7, hf, 5, s));
     if (norm_slots) {   // z-split smoother: one (L₁, L∞) pair per plane range
       static const int SD[3] = {2, 5, 6}, SF[3] = {1, 2, 3};
       double a = 0.0; float m = 0.f;
@@ -444,6 +452,13 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     if (rnew >= r1) w = (float)std::fmax(0.2, 0.9 * (double)w);                           // :118-119
     else if (rnew < r1) w = (float)std::fmin(1.0, 1.02 * (double)w);                      // :120-121
     r1 = rnew;
+    if (spec) {
+      // the device's flag IS the decision (same statements as below on the same two numbers; with check_head also the head's mean-shift test — if that one failed
+      // the caller discards this solve: stop here, the tail has not run)
+      if (check_head && np == 1 && !(std::fabs((float)hd[0] / (float)(double)wl_ninside_global(p.g)) <= 2.f * 1.1920929e-7f)) break;
+      if (hf[4] != 0.f) { tail_stood = true; break; }
+      continue;
+    }
     if ((double)r1 < r1tol && (double)rinf < rinftol) break;
   }
   WL_TRY(wl::bc_per_scalar(p.x, p.x_, perdir, s));                                        // :126

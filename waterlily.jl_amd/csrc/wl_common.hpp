@@ -204,7 +204,10 @@ struct BcFold { int on; float U[3];
                 // in: x of a projection whose velocity update was deferred to this conv_diff! launch (wl_convf.hip, PROJ); out: 1 = the launch applied it
                 const float* proj_x = nullptr; int proj_done = 0;
                 // in: BC!(u_in,U) was deferred — the producer of u_in wrote the interior only (wl_sim, mom_step!): the tail reads the wall-normal boundary faces as U
-                int usub = 0; };
+                int usub = 0;
+                // in: device flag — the tail kernel does nothing unless *go != 0 (the solver's convergence decision taken on the device: wl::decide_converged; the tail is
+                // queued behind the V-cycle before the host has read the norms)
+                const float* go = nullptr; };
 
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {
@@ -297,6 +300,7 @@ int resjac(float* xout, float* rout, const float* x, const float* u, const GridX
            bool shell = true, const float* bcU = nullptr);   // shell = false: x's (and x_out's) ghost cells are known to be +0 — the ghost-shell scaling pass is skipped
 int shell_nonzero(const float* a, const GridX& g, int* dev_flag, hipStream_t s);
 int project_unscale(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& cl, hipStream_t s, const BcFold* fold = nullptr);
+int decide_converged(const RedWs& ws, double r1tol, double rinftol, double ninside, int check_head, int slot_d, int slot_f, int out_slot, hipStream_t s);   // res_f[out_slot] = 1/0: solver!'s break test (and the fused head's mean-shift test) on the device
 bool project_cfl_pair_path(const GridX& g, const ConstL& cl);   // the two-cells-per-thread tail will run (the form that honours BcFold::usub)
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma = 1, const BcFold* fold = nullptr);
 int project_unscale_split(float* u, const float* L, const float* x, float* pout, const GridX& g, float dt, const ConstL& near, const ConstL& far, int na, int nb, hipStream_t s);

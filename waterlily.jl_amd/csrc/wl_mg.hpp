@@ -1,5 +1,6 @@
 // MultiLevelPoisson handle (struct src/MultiLevelPoisson.jl:61-77) — internal C++ definition behind `wl_mg`.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "wl_comm.hpp"
@@ -31,6 +32,10 @@ struct wl_mg {
   bool defer_shift = true;  // residual!'s mean shift and solver!'s first norms are folded into the finest level's Jacobi! (z-march kernel) when that is what runs next
   bool shift_pending = false;
   bool deep_halo = true;     // z-slabs with >= 5 ghost planes: one r exchange (5 planes) per smooth! instead of r (2) + ϵ_mid (3) + r' (2)
+  // One-shot hook of the next solve(): the projection tail, queued behind every iteration's smoother BEFORE the host reads that iteration's norms and gated on the
+  // device by the break test (wl::decide_converged → res_f[4], also the host's decision): no idle GPU while the host decides, nothing happens if the loop goes on.
+  // spec_check_head: the flag of the first iteration also requires the fused head's mean-shift test to pass (wl_sim's early V-cycle).  tail_stood: the tail ran.
+  std::function<int(const float*)> spec_tail; bool spec_check_head = false, tail_stood = false;
   double first_hd0 = 0.0;   // res_d[0] as the first iteration's read found it (the fused head's Σr when its check is deferred: wl_sim)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots

@@ -143,6 +143,7 @@ __device__ __forceinline__ float wl_dec_f(int k) { return __int_as_float(k >= 0 
 template <int D, int CL>
 __global__ void k_project_unscale(GridX g, float* __restrict__ u, const float* __restrict__ L, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl, int zchunk,
                                   int p0, int p1, BcFold bc, int lin) {   // local planes [p0,p1) of this launch; bc.on: BC!(u,U) folded into the stores (wl_bcfold.hpp); lin: linear block order (wl_tile_lin)
+  if (bc.go && *bc.go == 0.f) return;      // queued before the host knew whether the solve had converged: it had not
   int i, j; long m; int pz;
   if (lin) wl_tile_lin(g, m, pz); else wl_tile(g, m, pz);
   if (!cell_ij(g, m, i, j)) return;
@@ -251,6 +252,7 @@ __device__ __forceinline__ bool pl_pair(const GridX& g, long& m, int& k, int p0)
 static inline unsigned pl_grid(const GridX& g, int nplanes) { const long np2 = (g.sz / 2 + WL_BLOCK - 1) / WL_BLOCK; return (unsigned)((((np2 + 7) >> 3) << 3) * nplanes); }
 __global__ void __launch_bounds__(WL_BLOCK) k_project_unscale2(GridX g, float* __restrict__ u, const float* __restrict__ x, float* __restrict__ pout, float dt, wl::ConstL cl,
                                                                   int p0, int p1, BcFold bc) {
+  if (bc.go && *bc.go == 0.f) return;
   long m; int k;
   if (!pl_pair(g, m, k, p0) || k >= p1) return;
   const int j = (int)(m / g.nx), i0 = (int)(m - (long)j * g.nx);
@@ -278,6 +280,7 @@ __global__ void __launch_bounds__(WL_BLOCK) k_project_unscale2(GridX g, float* _
 __global__ void __launch_bounds__(WL_BLOCK) k_project_cfl2(GridX g, float* __restrict__ uout, const float* __restrict__ uin, const float* __restrict__ x, float* __restrict__ pout,
                                                               float* __restrict__ sigma, float dt, wl::ConstL cl, int kfirst, int klast, float* __restrict__ pmax, int p0, int p1,
                                                               int store_sigma, BcFold bc) {
+  if (bc.go && *bc.go == 0.f) return;      // (block-uniform; the maximum's slots keep k_enc_init's −∞)
   long m; int k;
   float mx = -INFINITY;
   if (pl_pair(g, m, k, p0) && k < p1) {
@@ -1131,6 +1134,7 @@ int project_unscale(float* u, const float* L, const float* x, float* pout, const
   const int zc = lin ? 1 : wl_march_chunk(g, g.nz);
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
+  bc.go = fold ? fold->go : nullptr;
   if (tail_pair() && lin && cl.on && (g.nx & 1) == 0 && g.k0 >= 1) {   // two cells per thread (k_project_unscale2): x[o−sz] of plane 0 is never read (k0 >= 1)
     hipLaunchKernelGGL(k_project_unscale2, dim3(pl_grid(g, g.nz)), dim3(WL_BLOCK), 0, s, g, u, x, pout, dt, cl, 0, g.nz, bc);
     WL_LAUNCH_CHECK(); return 0;
@@ -1150,6 +1154,19 @@ int project_unscale_split(float* u, const float* L, const float* x, float* pout,
   }
   WL_LAUNCH_CHECK(); return 0;
 }
+// solver!'s break test on the device (src/MultiLevelPoisson.jl:122 with l1n_tol, src/Poisson.jl:194): res_f[out_slot] = 1 if L₁ < r1tol ∧ L∞ < rinftol — the statements
+// wl_mg::solve evaluates on the host from the same two numbers — and, with check_head, the fused head's mean-shift test |Σr/N| ≤ 2eps (src/Poisson.jl:96) as well.
+// The host takes its decision from this flag (read back with the norms), so a tail kernel gated by it and the solver loop can never disagree.
+__global__ void k_decide(const double* __restrict__ res_d, float* __restrict__ res_f, double r1tol, double rinftol, double ninside, int check_head, int slot_d, int slot_f, int out_slot) {
+  const float rnew = (float)res_d[slot_d], rinf = res_f[slot_f];
+  bool ok = (double)rnew < r1tol && (double)rinf < rinftol;
+  if (check_head) { const float sm = (float)res_d[0] / (float)ninside; ok = ok && fabsf(sm) <= 2.f * 1.1920929e-7f; }
+  res_f[out_slot] = ok ? 1.f : 0.f;
+}
+int decide_converged(const RedWs& ws, double r1tol, double rinftol, double ninside, int check_head, int slot_d, int slot_f, int out_slot, hipStream_t s) {
+  hipLaunchKernelGGL(k_decide, dim3(1), dim3(1), 0, s, (const double*)ws.res_d, ws.res_f, r1tol, rinftol, ninside, check_head, slot_d, slot_f, out_slot);
+  WL_LAUNCH_CHECK(); return 0;
+}
 bool project_cfl_pair_path(const GridX& g, const ConstL& cl) { return (tail_pair_bits() & 2) && g.D == 3 && cl.on && (g.nx & 1) == 0 && g.k0 >= 1 && g.k1 <= g.nz - 1; }
 // projection tail + CFL's σ and max(σ) -> ws.res_f[slot_f]; u_out must not alias u_in
 int project_cfl(float* uout, const float* uin, const float* L, const float* x, float* pout, float* sigma, const GridX& g, float dt, const ConstL& cl, const RedWs& ws, int slot_f, hipStream_t s, int store_sigma, const BcFold* fold) {
@@ -1158,6 +1175,8 @@ int project_cfl(float* uout, const float* uin, const float* L, const float* x, f
   if (g.D == 3) { kfirst = (g.gk + g.k0 == 1) ? g.k0 - 1 : g.k0; klast = (g.gk + g.k1 == g.gnz - 1) ? g.k1 + 1 : g.k1; }
   BcFold bc{0, {0.f, 0.f, 0.f}};
   if (fold && fold->on && g.D == 3 && g.nz == g.gnz && g.nx >= 6 && g.ny >= 6 && g.nz >= 6) bc = *fold;
+  bc.go = fold ? fold->go : nullptr;
+  if (bc.go && !project_cfl_pair_path(g, cl)) { wl_set_error("project_cfl: a tail queued ahead of the convergence read needs the two-cells-per-thread form"); return WL_EINVAL; }
   if (fold && fold->usub && !(bc.on && project_cfl_pair_path(g, cl))) { wl_set_error("project_cfl: deferred BC! needs the folded two-cells-per-thread tail"); return WL_EINVAL; }
   if (project_cfl_pair_path(g, cl)) {   // two cells per thread, linear order (k_project_cfl2)
     hipLaunchKernelGGL(k_enc_init, dim3(1), dim3(WL_ENC_SLOTS), 0, s, reinterpret_cast<int*>(ws.pm));

@@ -488,6 +488,9 @@ struct wl_sim {
   int p_shell = -1;          // ghost shell of p / the spare pressure array: -1 unknown (check before the next fused head), 0 all +0, 1 something else, 2 caller-owned p (never assumed)
   bool use_fuse_cfl = true;  // the corrector's projection tail also produces CFL's σ and max(σ)
   bool cfl_done = false;
+  static constexpr int CFL_SLOT = 5;   // res_f slot of CFL's maximum (not slot 0: a tail queued ahead of the solver's read must leave the head's L∞ there for the log)
+  bool use_tailspec = true;  // the projection tail is queued behind the smoother before the host has read the norms, gated on the device by the break test (single GPU)
+  long n_tailspec = 0;
   int project(float w, hipStream_t s, bool with_cfl = false, bool defer_tail = false) {    // mom_project! :223-232 (defer_tail: inside mom_step!, the corrector follows)
     const float dtl = w * dt.back();
     cfl_done = false;
@@ -500,6 +503,34 @@ struct wl_sim {
       bool head_done = false;
       double pre_r1 = 0.0; float pre_rinf = 0.f;
       bool solved = false;      // the speculative solve behind the fused head stood
+      // ---- the tail, as a function of a device flag (go != nullptr: queued inside the solver loop ahead of its read — runs iff the flag says "converged")
+      const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
+      const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
+      int tail_kind = 0;        // 1: projection + flux_out + max σ into the spare array, 2: projection in place, 3: left to the corrector's loader
+      bool tail_stood = false;
+      auto launch_tail = [&](const float* go) -> int {
+        // (p is the solver's x by now, ps the array the unscaled pressure goes to: both solve() call sites swap before they call)
+        if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
+          tail_kind = 1;
+          if (split) { WL_TRY(flush_bc(s)); WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, CFL_SLOT, s, store_f ? 1 : 0)); }
+          else {
+            BcFold fr = fold_req(1);
+            if (bc_deferred && !(fr.on && wl::project_cfl_pair_path(G, l0.cl))) WL_TRY(flush_bc(s));
+            fr.usub = bc_deferred ? 1 : 0;      // flux_out reads the wall-normal boundary faces of the corrector's output: U on load
+            fr.go = go;
+            WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, CFL_SLOT, s, store_f ? 1 : 0, &fr)); bc_folded = fr.on != 0;
+          }
+        } else if (split) { tail_kind = 2; WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s)); }
+        else if (defer_tail && tailfuse_ok()) {   // p = x/Δt now; u −= L∇x and BC! when the corrector reads u (the scaled x stays untouched in the spare pressure array until then)
+          tail_kind = 3;
+          WL_TRY(wl::div_scalar_to(ps, p, dtl, (size_t)G.cs, s));
+        }
+        else { tail_kind = 2; BcFold fr = fold_req(1); fr.go = go; WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s, &fr)); bc_folded = fr.on != 0; }
+        return 0;
+      };
+      // the forms that honour the flag: the in-place tail and the pair tail with CFL (not the z-split of a body, not the corrector-loader form)
+      const bool tail_gateable = !split && !(defer_tail && tailfuse_ok()) &&
+                                 (!(with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) || (wl::project_cfl_pair_path(G, l0.cl) && (!bc_deferred || fold_req(1).on)));
       if (use_resjac && !resjac_backoff && !d.exitBC && !store_f && !d.perdir_mask && !l0.part && mg->defer_shift && mg->lv.size() > 1 && wl::resjac_ok(G, l0.cl) &&
           (!comm || (l0.dist && mg->x_halo_depth >= 2))) {   // (exitBC: the convective exit leaves a net flux imbalance to the solver's tolerance — the shift is usually due; z-slab: p's ghost planes are current two deep)
         // head + the V-cycle's first Jacobi!(fine) in one launch, assuming residual!'s mean shift is not due (wl_resjac.hip); Σr decides
@@ -515,7 +546,9 @@ struct wl_sim {
           std::swap(p, ps); l0.x = p;
           std::swap(l0.r, l0.eps);
           mg->jacobi0_done = true;
+          if (use_tailspec && tail_gateable && !resjac_force_redo) { mg->spec_tail = launch_tail; mg->spec_check_head = true; }
           WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s, true, nullptr, nullptr));
+          tail_stood = mg->tail_stood; if (tail_stood) n_tailspec++;
           const float sm = (float)mg->first_hd0 / (float)(double)wl_ninside_global(mg->lv[0].g);
           if (std::fabs(sm) <= 2.f * 1.1920929e-7f && !resjac_force_redo) { head_done = true; solved = true; n_resjac++; resjac_redo_run = 0; }
           else {
@@ -550,31 +583,21 @@ struct wl_sim {
       if (!head_done) { std::swap(p, ps); l0.x = p; }
       if (!solved) WL_TRY(mg->solve(2e-3, itmx, nullptr, nullptr, nullptr, s, true, head_done ? &pre_r1 : nullptr, head_done ? &pre_rinf : nullptr));
       // tail: u -= L∇x ; x./=dt in one pass — the unscaled pressure goes back to the original array
-      const bool split = l0.part && mg->use_zsplit && !comm;        // a body: the three plane ranges of the z-split (see above)
-      const int zm = 4, zna = split ? std::max(l0.g.k0, l0.za - zm) : 0, znb = split ? std::min(l0.g.k1, l0.zb + zm + 1) : 0;
-      if (with_cfl && use_fuse_cfl && us && !d.exitBC && !d.perdir_mask) {   // + flux_out and its maximum; projected u lands in the spare array
-        if (split) { WL_TRY(flush_bc(s)); WL_TRY(wl::project_cfl_split(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, l0.clp, zna, znb, mg->ws, 0, s, store_f ? 1 : 0)); }
-        else {
-          BcFold fr = fold_req(1);
-          if (bc_deferred && !(fr.on && wl::project_cfl_pair_path(G, l0.cl))) WL_TRY(flush_bc(s));
-          fr.usub = bc_deferred ? 1 : 0;      // flux_out reads the wall-normal boundary faces of the corrector's output: U on load
-          WL_TRY(wl::project_cfl(us, u, mu0, p, ps, sigma, G, dtl, l0.cl, mg->ws, 0, s, store_f ? 1 : 0, &fr)); bc_folded = fr.on != 0;
-          bc_deferred = false;                // the folded stores wrote every boundary location of the new u
-        }
-        WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
-        std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
-      } else if (split) WL_TRY(wl::project_unscale_split(u, mu0, p, ps, G, dtl, l0.cl, l0.clp, zna, znb, s));
-      else if (defer_tail && tailfuse_ok()) {   // p = x/Δt now; u −= L∇x and BC! when the corrector reads u (the scaled x stays untouched in the spare pressure array until then)
-        WL_TRY(wl::div_scalar_to(ps, p, dtl, (size_t)G.cs, s));
+      if (!tail_stood) WL_TRY(launch_tail(nullptr));
+      if (tail_kind == 3) {   // deferred into the corrector's loader (tailfuse)
         bc_deferred = false;                  // (the corrector's loader reads this u through the projection AND BC!: nothing in memory is missing)
         proj_pending = p;
         std::swap(p, ps); l0.x = p;
         n_tailfuse++;
         return 0;
       }
-      else { const BcFold fr = fold_req(1); WL_TRY(wl::project_unscale(u, mu0, p, ps, G, dtl, l0.cl, s, &fr)); bc_folded = fr.on != 0; }
+      if (tail_kind == 1) {
+        bc_deferred = false;                  // the folded stores wrote every boundary location of the new u
+        WL_TRY(wl::combine_results(comm, mg->ws, s));   // max over ranks — issued BEFORE the u exchange starts on the other stream, so that
+        std::swap(u, us); cfl_done = true;              // exchange stays in flight across the Δt read-back and the next predictor's interior
+      }
       std::swap(p, ps); l0.x = p;
-      bc_deferred = false;      // the tails above update a cell from its own value only; whatever BC! had not been applied is applied now (folded stores or bc_u)
+      bc_deferred = false;      // the tails update a cell from its own value only; whatever BC! had not been applied is applied now (folded stores or bc_u)
       return bc_u(s);
     }
     WL_TRY(flush_bc(s));
@@ -585,9 +608,9 @@ struct wl_sim {
     return bc_u(s);
   }
   int cfl(hipStream_t s) {                                                               // CFL :234-237
-    if (!cfl_done) { WL_TRY(sync_u(s)); WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, 0, s)); WL_TRY(wl::combine_results(comm, mg->ws, s)); }   // max over ranks
+    if (!cfl_done) { WL_TRY(sync_u(s)); WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, CFL_SLOT, s)); WL_TRY(wl::combine_results(comm, mg->ws, s)); }   // max over ranks
     cfl_done = false;
-    float mx; WL_TRY(wl::read_results(mg->ws, nullptr, 0, &mx, 1, s));
+    float hf6[CFL_SLOT + 1]; WL_TRY(wl::read_results(mg->ws, nullptr, 0, hf6, CFL_SLOT + 1, s)); const float mx = hf6[CFL_SLOT];
     dt.push_back(std::fmin(10.f, 1.0f / (mx + 5 * d.nu)));
     return 0;
   }
@@ -838,6 +861,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2 || value == 3; s->redo_unannounced = value == 3; return 0; }   // 2: always take the redo path (tests); 3: the same, unknown to the BC! deferral (tests: its flush before the two-kernel head)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "tailspec") { s->use_tailspec = value != 0; return 0; }                             // the projection tail is queued ahead of the solver's convergence read, gated by the device's break test (default 1)
   if (n == "headspec") { s->use_headspec = value != 0; return 0; }                             // the first V-cycle is queued behind the fused head before Σr is known (default 1)
   if (n == "bcdefer") { s->use_bcdefer = value != 0; return 0; }                               // mom_step!: BC! after the fused conv_diff!+BDIM! left to the projection (its head reads U on the wall-normal faces, its tail rewrites the boundary); default 1
   if (n == "tailfuse") { s->use_tailfuse = value != 0; return 0; }                             // mom_step!: the first projection's u −= L∇x + BC! inside the corrector's conv_diff! (default 0: no gain measured)
@@ -866,6 +890,7 @@ int wl_sim_counter(wl_sim* s, const char* name, long* out) {
   if (n == "resjac_backoff") { *out = s->resjac_backoff ? 1 : 0; return 0; }
   if (n == "tailfuse") { *out = s->n_tailfuse; return 0; }
   if (n == "bcdefer") { *out = s->n_bcdefer; return 0; }
+  if (n == "tailspec") { *out = s->n_tailspec; return 0; }
   if (n == "xdefer") { *out = s->mg->last_xdefer; return 0; }
   wl_set_error("unknown counter " + n); return WL_EINVAL;
 }

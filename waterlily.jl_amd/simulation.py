@@ -232,7 +232,7 @@ class FusedSimulation:
         check(lib().wl_sim_set_option(self._h, name.encode(), int(value)))
 
     def counter(self, name):
-        """path counters of the handle (include/wlhip_bench.h wl_sim_counter): "resjac", "resjac_redo", "resjac_backoff", "xdefer", "tailfuse", "bcdefer" """
+        """path counters of the handle (include/wlhip_bench.h wl_sim_counter): "resjac", "resjac_redo", "resjac_backoff", "xdefer", "tailfuse", "bcdefer", "tailspec" """
         v = C.c_long(0)
         check(lib().wl_sim_counter(self._h, name.encode(), C.byref(v)))
         return int(v.value)
