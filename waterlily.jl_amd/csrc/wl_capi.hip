@@ -133,7 +133,7 @@ int wl_mg::build(float* x, float* L, float* z, const wl_grid& g0, unsigned per, 
   WL_HIP(hipStreamSynchronize(s));
   return 0;
 }
-wl_mg::~wl_mg() { if (slab) (void)hipFree(slab); if (red) (void)hipFree(red); }
+wl_mg::~wl_mg() { if (slab) (void)hipFree(slab); if (red) (void)hipFree(red); if (side) (void)hipStreamDestroy(side); if (ev_decided) (void)hipEventDestroy(ev_decided); }
 
 // coarse face coefficients of level l from level l-1 (restrictL! :42-48), slab aware
 static int restrictL_level(wl_mg& m, size_t l, hipStream_t s) {
@@ -416,7 +416,7 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     shift_pending = !jacobi0_done && defer_shift && itmx >= 1 && !(comm && comm->size > 1) && !perdir && lv.size() > 1 && wl::jacobi_takes_shift(p.x_, p.cl);
     if (!shift_pending && !jacobi0_done) WL_TRY(wl::shift_norms_dev(p.r, p.x_, ws, 1, 0, s));
   }
-  double hd[7]; float hf[4];
+  double hd[8]; float hf[8];
   float w = 1.f;
   // r₁ of the initial residual is only needed for the ω rule after the first V-cycle: fetched with the first iteration's norms
   bool have_r1 = false; float r1 = 0.f, rinf = 0.f;
@@ -436,8 +436,10 @@ int wl_mg::solve(double tol, int itmx, int* host_n, double* host_r1, float* host
     const bool spec = (bool)tail && norm_slots == 0 && !comm;
     if (spec) {   // the break test on the device, and the projection tail behind it: runs iff this iteration is the last one
       WL_TRY(wl::decide_converged(ws, r1tol, rinftol, (double)wl_ninside_global(p.g), (check_head && np == 0) ? 1 : 0, 2, 1, 4, s));
-      WL_TRY(tail(ws.res_f + 4));
-    }
+      if (!ev_decided) WL_HIP(hipEventCreateWithFlags(&ev_decided, hipEventDisableTiming));
+      const float* go = ws.res_f + 4;
+      WL_TRY(wl::read_results_overlapped(ws, hd, 7, hf, 5, s, ev_decided, [&]() -> int { return tail(go); }));   // the copy of the norms sits between the decision and the tail: the host wakes for the copy and goes on queueing work behind the running tail
+    } else
     WL_TRY(wl::read_results(ws, hd, 7, hf, 5, s));
     if (norm_slots) {   // z-split smoother: one (L₁, L∞) pair per plane range
       static const int SD[3] = {2, 5, 6}, SF[3] = {1, 2, 3};

@@ -1,5 +1,6 @@
 // Shared device/host helpers for libwlhip (gfx950 only; wave = 64).
 #pragma once
+#include <functional>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -233,6 +234,7 @@ int l1_linf_dev(const float* a, size_t n, const RedWs& ws, int slot_d, int slot_
 int max_dev(const float* a, size_t n, const RedWs& ws, int slot_f, hipStream_t s);
 int dot_dev(const float* a, const float* b, size_t n, const RedWs& ws, int slot, hipStream_t s);
 int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s);
+int read_results_overlapped(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s, hipEvent_t copied, const std::function<int()>& queue_behind);   // work queued behind the copy before the host waits for the copy alone
 std::mutex& wl_read_mutex();   // guards the process-wide pinned staging scalars of WlCtx
 
 int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per, hipStream_t s);

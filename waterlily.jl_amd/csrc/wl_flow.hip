@@ -1,6 +1,7 @@
 // Flow-side kernels for gfx950: conv_diff! (gather form), BDIM!, BC!, div, projection, CFL and the
 // generic array ops.  Reference semantics: /root/reference/src/Flow.jl, src/core.jl (file:line per kernel).
 // Arithmetic order follows the reference statement by statement (-ffp-contract=off).
+#include <functional>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -621,6 +622,20 @@ int read_results(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStre
   for (int q = 0; q < nd; q++) hd[q] = c.h_d[q];
   for (int q = 0; q < nf; q++) hf[q] = c.h_f[q];
   return 0;
+}
+
+// the same read-back, with more work queued on the stream BEHIND the copy before the host waits — for the copy only (an event), not for that work
+int read_results_overlapped(const RedWs& ws, double* hd, int nd, float* hf, int nf, hipStream_t s, hipEvent_t copied, const std::function<int()>& queue_behind) {
+  std::lock_guard<std::mutex> lock(wl_read_mutex());
+  WlCtx& c = wl_ctx();
+  if (!(nd > 0 && nf > 0 && (const char*)ws.res_f == (const char*)ws.res_d + 64 && nd <= 8 && nf <= 16)) { wl_set_error("read_results_overlapped: layout"); return WL_EINVAL; }
+  WL_HIP(hipMemcpyAsync(c.h_d, ws.res_d, 64 + sizeof(float) * (size_t)nf, hipMemcpyDeviceToHost, s));
+  WL_HIP(hipEventRecord(copied, s));
+  const int rc = queue_behind();
+  WL_HIP(hipEventSynchronize(copied));
+  for (int q = 0; q < nd; q++) hd[q] = c.h_d[q];
+  for (int q = 0; q < nf; q++) hf[q] = c.h_f[q];
+  return rc;
 }
 
 int bc_vec(float* a, const GridX& g, const float* U, int saveexit, unsigned per, hipStream_t s) {

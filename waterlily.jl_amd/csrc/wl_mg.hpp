@@ -36,6 +36,7 @@ struct wl_mg {
   // device by the break test (wl::decide_converged → res_f[4], also the host's decision): no idle GPU while the host decides, nothing happens if the loop goes on.
   // spec_check_head: the flag of the first iteration also requires the fused head's mean-shift test to pass (wl_sim's early V-cycle).  tail_stood: the tail ran.
   std::function<int(const float*)> spec_tail; bool spec_check_head = false, tail_stood = false;
+  hipStream_t side = nullptr; hipEvent_t ev_decided = nullptr;   // the host waits for the copy of such an iteration's norms (this event), not for the tail queued behind it
   double first_hd0 = 0.0;   // res_d[0] as the first iteration's read found it (the fused head's Σr when its check is deferred: wl_sim)
   bool jacobi0_done = false; // the fused projection head (wl_resjac.hip) already ran the V-cycle's first Jacobi! on the finest level and left solver!'s first norms
   int norm_slots = 0;       // z-split smoother: which plane ranges left an (L₁, L∞) pair in their own result slots
