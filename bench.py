@@ -274,8 +274,7 @@ def main():
     for key, val in os.environ.items():      # A/B switches for experiments: WL_OPT_<option of wl_sim_set_option>=0/1 (defaults: fast paths on)
         if key.startswith("WL_OPT_"):
             sim.set_option(key[7:], int(val))
-    for _ in range(args.warmup):
-        sim.mom_step_()
+    sim.mom_steps_(args.warmup)      # wl_sim_mom_steps: the K steps of the timed region are ONE library call too (same results as K calls of wl_sim_mom_step)
     sim.sync()
     n_warm = len(sim.pois_n)
     all_phases = args.phases or (any(k.startswith("WL_OPT_") for k in os.environ) and not args.no_phases)
@@ -287,8 +286,7 @@ def main():
     l0, rj0, rd0 = int(lib.wl_launch_count()), counter("resjac"), counter("resjac_redo")
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sim.mom_step_()
+    sim.mom_steps_(args.steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     launches_per_step = (int(lib.wl_launch_count()) - l0) / args.steps

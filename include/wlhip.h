@@ -200,6 +200,7 @@ int wl_sim_init_flow(wl_sim* s, void* stream);          /* BC!(u), u⁰=u, μ₀
    bit 0 the projection tails, bit 1 the tiled conv_diff!+BDIM! (measured slower: off by default)
    "resjac"[1] projection head (div, x·=dt, residual!) + the V-cycle's first Jacobi! in one launch on single-domain NoBody levels (the
    mean shift is checked on the host afterwards; if due, the two-kernel path is taken)   "resjac_min"[6 Mi cells] size gate (tests: 0)
+   "lazydt"[1] wl_sim_mom_steps: see there
    "tailspec"[1] the projection tail is queued behind the smoother before the host has read that iteration's norms and gated on the device by solver!'s break test
        (the flag the host then takes its own decision from): it runs iff the iteration was the last one.  Single GPU, the in-place tail and the pair tail with CFL.
    "headspec"[1] the solver's first V-cycle is queued behind the fused projection head before Σr (residual!'s mean-shift test) has been read back — solver! runs at
@@ -228,6 +229,10 @@ int wl_sim_set_forcing(wl_sim* s, const float* U1, const float* a0, const float*
 int wl_accelerate(float* r, const wl_grid* g, const float a[3], void* stream);   /* accelerate! for a uniform acceleration: r[I,i] += a_i */
 int wl_sim_update(wl_sim* s, void* stream);             /* update!(pois) after μ₀ changed (measure!, src/WaterLily.jl:148) */
 int wl_sim_mom_step(wl_sim* s, void* stream);           /* mom_step!(flow,pois): appends Δt */
+/* n × mom_step! in one call — the loop of sim_step!(sim,t_end) without measure! (src/WaterLily.jl:136-139 with remeasure=false).  Same results as n calls of
+   wl_sim_mom_step; between its steps the library may keep Δt on the device until the next predictor has been queued (option "lazydt"): one host round trip per
+   step fewer.  The Δt history is complete when the call returns. */
+int wl_sim_mom_steps(wl_sim* s, int n, void* stream);
 int wl_sim_dt(const wl_sim* s, float* host_out, int cap);      /* flow.Δt (host vector, src/Flow.jl:127) */
 double wl_sim_time(const wl_sim* s);                    /* time(flow) = sum(Δt[1:end-1]) :174 */
 float wl_sim_dt_last(const wl_sim* s);                 /* Δt[end] */

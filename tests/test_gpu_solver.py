@@ -936,6 +936,41 @@ def test_tiled_conv_diff_is_bit_identical(w, oracle, dims, lam):
     assert np.abs(res["flux"][1] - outo[1]).max() < 2e-5
 
 
+@pytest.mark.parametrize("dims", [(64, 32, 24), (130, 34, 16), (128, 48, 12)])
+def test_mom_steps_equals_repeated_mom_step(w, oracle, dims):
+    """wl_sim_mom_steps(n) — between its steps Δt stays on the device until the next predictor has been queued (option lazydt: the predictor reads it through a
+    pointer, the host copies the CFL maximum while it runs) — against n calls of wl_sim_mom_step, with the option on and off: u, u⁰, p on every cell, pois.n and the
+    whole Δt history bit for bit, a second batch of steps included (the history must be complete whenever a call returns)."""
+    rng = np.random.default_rng(73)
+    Ng = tuple(n + 2 for n in dims)
+    uBC = (0.3, -0.2, 0.1)
+    u_init = np.asfortranarray(rng.uniform(-0.4, 0.4, size=Ng + (3,)).astype(np.float32))
+    res = {}
+    for mode in ("single", "batch", "batch_nolazy"):
+        sg = w.FusedSimulation(dims, uBC, dims[0], U=1, nu=0.02, u0=u_init)
+        sg.set_option("convt_min", 0)
+        sg.set_option("resjac_min", 0)
+        sg.set_option("lazydt", 0 if mode == "batch_nolazy" else 1)
+        if mode == "single":
+            for _ in range(5):
+                sg.mom_step_()
+            mid = sg.dt
+            for _ in range(2):
+                sg.mom_step_()
+        else:
+            sg.mom_steps_(5)
+            mid = sg.dt
+            sg.mom_steps_(2)
+        res[mode] = (sg.field("u"), sg.field("u0"), sg.field("p"), sg.pois_n, sg.dt, mid)
+        sg.set_option("convt_min", 8192)
+        sg.set_option("resjac_min", 8 << 20)
+    assert len(res["single"][4]) == 8 and len(res["single"][5]) == 6
+    for mode in ("batch", "batch_nolazy"):
+        assert res[mode][3] == res["single"][3] and res[mode][4] == res["single"][4] and res[mode][5] == res["single"][5], mode
+        for q in range(3):
+            assert np.array_equal(res[mode][q], res["single"][q]), (mode, ("u", "u0", "p")[q])
+
+
 @pytest.mark.parametrize("dims", [(64, 32, 24), (72, 40, 16), (128, 48, 12)])
 def test_tail_queued_ahead_of_the_convergence_read_is_bit_identical(w, oracle, dims):
     """The projection tail queued behind the smoother BEFORE the host has read that iteration's norms, gated on the device by solver!'s break test (and, on the

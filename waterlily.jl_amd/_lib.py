@@ -121,6 +121,7 @@ SIGNATURES = {
     "wl_sim_set_forcing": (i32, [P, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]),
     "wl_accelerate": (i32, [P, G, C.POINTER(f32), P]),
     "wl_sim_mom_step": (i32, [P, P]),
+    "wl_sim_mom_steps": (i32, [P, i32, P]),
     "wl_sim_dt": (i32, [P, C.POINTER(f32), i32]),
     "wl_sim_time": (f64, [P]),
     "wl_sim_dt_last": (f32, [P]),

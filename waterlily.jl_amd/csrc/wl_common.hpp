@@ -208,7 +208,10 @@ struct BcFold { int on; float U[3];
                 int usub = 0;
                 // in: device flag — the tail kernel does nothing unless *go != 0 (the solver's convergence decision taken on the device: wl::decide_converged; the tail is
                 // queued behind the V-cycle before the host has read the norms)
-                const float* go = nullptr; };
+                const float* go = nullptr;
+                // in (conv_diff!+BDIM! launches): Δt is read from this device location instead of the argument (wl_sim_mom_steps: the next step's predictor is queued
+                // before the host has read the CFL maximum); honoured by the flux-once tiled kernel only
+                const float* dt_dev = nullptr; };
 
 // ---- kernel launchers shared between the leaf C ABI and the composite handles --------------------
 namespace wl {

@@ -139,7 +139,8 @@ struct BdimArgs { const float* u0; const float* mu0; float* uout; float dt, pre,
                   const unsigned char* near; const unsigned char* needf; int nbm; int store_all;
                   const unsigned char* m0var;      // m0var: 1 = μ₀ deviates from "1 inside, 0 on wall faces" somewhere in the workgroup's cells
                   int bc_on; float bcU[3];         // BC!(u_out, U) folded into the stores (wl_bcfold.hpp): only the tiled kernel honours it
-                  const float* px; };              // flux-once kernel only (wl_convf.hip, PROJ): the advecting field is u* − L∇x with BC!(·,bcU), x = px; bcU is then set even when bc_on = 0
+                  const float* px;
+                  const float* dt_dev; };          // flux-once kernel only: Δt read from the device (BcFold::dt_dev); `dt` is ignored then              // flux-once kernel only (wl_convf.hip, PROJ): the advecting field is u* − L∇x with BC!(·,bcU), x = px; bcU is then set even when bc_on = 0
 // FUSE epilogue shared by both kernels: f = u⁰ + Δt·r (all cells) ; u_out = (u·pre + μ₀·f)·post (interior)      BDIM! NoBody, src/Flow.jl:176-180
 template <int D, typename IDX>
 __device__ __forceinline__ void cd_store(const GridX& g, float* __restrict__ r, const float* __restrict__ u, IDX o, const int* I, const int* N, bool in, const float* out, int fuse, const BdimArgs& bd) {

@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
     for (int cc = 0; cc < 3; cc++) Zm1[cc] = C1[cc];
     __syncthreads();       // nobody still reads plane ks−1 when the first iteration overwrites its slot
   }
+  const float dtv = bd.dt_dev ? *bd.dt_dev : bd.dt;      // (block-uniform scalar load)
   const int N[3] = {g.nx, g.ny, g.gnz};
   // μ₀ along x and y for the two cells (loop invariant; used by the wall tiles only)      Julia indices of the cells: (x+1, y+1), (x+2, y+1)
   const float mw[2][2] = {{wl::wl_cl_coef(x + 1, N[0], bd.cl_c[0]), wl::wl_cl_coef(x + 2, N[0], bd.cl_c[0])}, {wl::wl_cl_coef(y + 1, N[1], bd.cl_c[1]), wl::wl_cl_coef(y + 1, N[1], bd.cl_c[1])}};
@@ -383,7 +384,7 @@ __global__ void __launch_bounds__(CF_N, 4) k_conv_flux(GridX g, const float* __r
         const float m00 = a == 2 ? mz : (WALLS ? mw[a][0] : bd.cl_c[a]), m01 = a == 2 ? mz : (WALLS ? mw[a][1] : bd.cl_c[a]);
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          const float fn = cf_sel(u0a, e) + bd.dt * acc[e] - 0.f;
+          const float fn = cf_sel(u0a, e) + dtv * acc[e] - 0.f;
           const float xx = (0.f / 2 + 0.f) + (e ? m01 : m00) * fn;
           float v;
           if (MODE == 1) v = xx;

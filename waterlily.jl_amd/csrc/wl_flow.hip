@@ -720,10 +720,11 @@ static int conv_diff_launch2(float* r, const float* u, float* Phi, const GridX& 
       bt.px = fold->proj_x; for (int c = 0; c < 3; c++) bt.bcU[c] = fold->U[c];
       fold->proj_done = 1;
     }
+    if (fold && fold->dt_dev) { if (!wl::conv_flux_on()) { wl_set_error("conv_diff_bdim: Δt on the device needs the flux-once kernel"); return WL_EINVAL; } bt.dt_dev = fold->dt_dev; }
     WL_TRY(wl::conv_tile(u, g, nu, SCH, own_a, own_b, &bt, s));
     if (foldok) WL_TRY(wl::bc_zplanes(bt.uout, g, fold->U[2], s));
     if (fold) fold->on = foldok ? 1 : 0;
-  } else if (fold) fold->on = 0;
+  } else if (fold) { if (fold->dt_dev) { wl_set_error("conv_diff_bdim: Δt on the device needs the tiled kernel"); return WL_EINVAL; } fold->on = 0; }
   const bool march = !tiled && D == 3 && wl::conv_march_ok(g);   // z-marching variant (wl_convm.hip): same arithmetic, the z-star in registers
   if (march && !(bd && bd->near)) WL_TRY(wl::conv_march(r, u, g, nu, per, SCH, kfirst, klast, bd, s));
 #define WL_CD(PERF, IDXT, FUSEF)                                                                                                                  \

@@ -271,6 +271,8 @@ __global__ void k_exit_update_slab(GridX g, float* __restrict__ u, const float* 
   if (mode == 0) { const float U = (float)sc[0]; u[o] = u0[o] - U * dt * (u0[o] - u0[o - 1]); }
   else u[o] -= (float)sc[1];
 }
+// Δt = min(10, 1/(max σ + 5ν))  (src/Flow.jl:166, CFL :234-237) on the device: the statement wl_sim::cfl evaluates on the host from the same maximum
+__global__ void k_dt_from_cfl(float* __restrict__ res_f, int in_slot, int out_slot, float nu) { res_f[out_slot] = fminf(10.f, 1.0f / (res_f[in_slot] + 5 * nu)); }
 template <int D>
 __global__ void k_exit_update(GridX g, float* __restrict__ u, const float* __restrict__ u0, const double* __restrict__ sc, float dt, int mode) {
   const int ny = g.ny - 2;
@@ -329,10 +331,11 @@ struct wl_sim {
   bool store_f = false;      // the fused paths materialise the intermediates f = u⁰+Δt·r and z = ∇·u only on request: nothing on the time-step path reads them again
   // want_q1: also leave conv_diff!'s stale Φ in σ's ghost cells (quirk Q1: CFL's maximum(σ) sees them) — one small launch.  The predictor's are dead inside
   // mom_step!: the corrector's conv_diff! overwrites every one of them before anything reads σ's ghost cells.
-  int conv_fused(const float* uadv, float* uout, float pre, float post, hipStream_t s, bool want_q1 = true) {
+  int conv_fused(const float* uadv, float* uout, float pre, float post, hipStream_t s, bool want_q1 = true, const float* dt_dev = nullptr) {
     const wl::ConstL& cl = mg->lv[0].cl;
     float* f = store_f ? this->f : nullptr;
     if (u_pending && G.D == 3 && G.k1 - G.k0 > 4) {
+      if (dt_dev) { wl_set_error("conv_fused: Δt on the device is for the single domain"); return WL_EINVAL; }
       WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, G.k0 + 2, G.k1 - 2, false));
       WL_TRY(sync_u(s));
       WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), G.k0 + 2, false));
@@ -341,6 +344,7 @@ struct wl_sim {
     WL_TRY(sync_u(s));
     BcFold fr = fold_req(2);
     fr.proj_x = proj_pending;
+    fr.dt_dev = dt_dev;
     WL_TRY(wl::conv_diff_bdim(f, uadv, sigma, u0, mu0, uout, G, d.nu, d.perdir_mask, d.scheme, dt.back(), pre, post, cl, s, -(1 << 30), 1 << 30, want_q1, &fr));
     if (proj_pending && !fr.proj_done) { wl_set_error("mom_step!: the corrector did not take the deferred projection"); return WL_EINVAL; }
     proj_pending = nullptr;
@@ -431,7 +435,7 @@ struct wl_sim {
     bc_deferred = false;
     return wl::bc_vec(u, G, d.uBC, d.exitBC, d.perdir_mask, s);
   }
-  int predict(hipStream_t s) {                                                           // mom_predict! src/Flow.jl:190-196
+  int predict(hipStream_t s, const float* dt_dev = nullptr) {                            // mom_predict! src/Flow.jl:190-196 (dt_dev: Δt still on the device — lazydt_ok() paths only)
     if (hybrid_ok()) {
       WL_TRY(conv_bdim_body(u0, u, 0.f, 1.f, s));
       return bc_u(s);
@@ -443,7 +447,7 @@ struct wl_sim {
         WL_TRY(sync_u(s));
         WL_TRY(wl::conv_diff_z(store_f ? f : nullptr, u0, u0, mu0, u, G, d.nu, d.scheme, dt.back(), 0.f, 1.f, s));
         WL_TRY(wl::conv_q1(sigma, u0, G, d.nu, d.perdir_mask, d.scheme, s));
-      } else { WL_TRY(conv_fused(u0, u, 0.f, 1.f, s, !(in_step && !store_f))); fused_conv = true; }
+      } else { WL_TRY(conv_fused(u0, u, 0.f, 1.f, s, !(in_step && !store_f), dt_dev)); fused_conv = true; }
     } else {
       { ProfScope pc(WL_PROF_CONVDIFF, s); WL_TRY(conv_only(u0, s)); }
       if (forcing) WL_TRY(wl::accelerate(f, G, acc0, s));                                  // accelerate!(f,t₀,g,uBC)
@@ -607,26 +611,47 @@ struct wl_sim {
     WL_TRY(wl::div_scalar(p, dtl, (size_t)G.cs, s));                                     // x./=dt
     return bc_u(s);
   }
-  int cfl(hipStream_t s) {                                                               // CFL :234-237
+  // Δt of the NEXT step left on the device (wl_sim_mom_steps only: more steps follow inside the same call, nobody can look at the history in between): the finaliser
+  // of CFL's maximum is followed by a one-thread kernel with mom_step!'s formula, the next predictor reads Δt through a pointer and is queued at once; the host
+  // copies the maximum while that predictor runs and appends the same Δt to the history (same statements on the same number: same bits).
+  bool use_lazydt = true, dt_pending = false;
+  hipEvent_t ev_dt = nullptr;
+  bool lazydt_ok() const {      // the next predictor will be the flux-once tiled launch on the single domain
+    return use_lazydt && in_step && !comm && us && !d.has_body && !forcing && !use_convz && !d.exitBC && !d.perdir_mask && !store_f && wl::conv_flux_on() &&
+           wl::conv_tile_ok(G, d.perdir_mask, G.k1 - G.k0) && mg->lv[0].cl.on;
+  }
+  int cfl(hipStream_t s, bool more_follow = false) {                                     // CFL :234-237
     if (!cfl_done) { WL_TRY(sync_u(s)); WL_TRY(wl::cfl_dev(u, sigma, G, mg->ws, CFL_SLOT, s)); WL_TRY(wl::combine_results(comm, mg->ws, s)); }   // max over ranks
     cfl_done = false;
+    if (more_follow && lazydt_ok()) {
+      hipLaunchKernelGGL(k_dt_from_cfl, dim3(1), dim3(1), 0, s, mg->ws.res_f, CFL_SLOT, CFL_SLOT + 1, d.nu);
+      dt_pending = true;
+      return 0;
+    }
     float hf6[CFL_SLOT + 1]; WL_TRY(wl::read_results(mg->ws, nullptr, 0, hf6, CFL_SLOT + 1, s)); const float mx = hf6[CFL_SLOT];
     dt.push_back(std::fmin(10.f, 1.0f / (mx + 5 * d.nu)));
     return 0;
   }
-  int mom_step(hipStream_t s) {                                                          // mom_step! :156-167
+  int mom_step(hipStream_t s, bool more_follow = false) {                                // mom_step! :156-167 (more_follow: wl_sim_mom_steps — another step comes inside the same call)
     ProfScope pstep(WL_PROF_STEP, s);
     // u⁰ .= u ; scale_u!(a,0): when the handle owns both arrays the copy is a pointer swap — the predictor overwrites
     // every interior cell of u (BDIM! with pre=0) and BC! every ghost cell, so nothing of the old u survives anyway.
     if (swap_ok) { std::swap(u, u0); if (d.exitBC) WL_TRY(copy_exit_face(u, u0, s)); }   // (an exchange still in flight belongs to the array that is now u⁰ — the predictor's advecting field)
     else { WL_TRY(sync_u(s)); WL_HIP(hipMemcpyAsync(u0, u, sizeof(float) * (size_t)G.cs * d.D, hipMemcpyDeviceToDevice, s)); }   // u⁰ .= u
     struct InStep { bool& f; InStep(bool& b) : f(b) { f = true; } ~InStep() { f = false; } } guard(in_step);
+    if (dt_pending) {   // the CFL maximum of the previous step is copied back between ITS finaliser and THIS predictor, which takes Δt from the device
+      if (!ev_dt) WL_HIP(hipEventCreateWithFlags(&ev_dt, hipEventDisableTiming));
+      double hd1[1]; float hf7[CFL_SLOT + 2];
+      WL_TRY(wl::read_results_overlapped(mg->ws, hd1, 1, hf7, CFL_SLOT + 2, s, ev_dt, [&]() -> int { return predict(s, mg->ws.res_f + CFL_SLOT + 1); }));
+      dt.push_back(std::fmin(10.f, 1.0f / (hf7[CFL_SLOT] + 5 * d.nu)));
+      dt_pending = false;
+    } else
     WL_TRY(predict(s));
     WL_TRY(project(1.f, s, false, true));
     WL_TRY(correct(s));
     WL_TRY(project(0.5f, s, true));
     WL_TRY(flush_bc(s));      // (nothing is pending here: every projection ends with BC! applied — guard)
-    return cfl(s);
+    return cfl(s, more_follow);
   }
 };
 int wl_sim::copy_exit_face(float* dst, const float* src, hipStream_t s) {
@@ -861,6 +886,7 @@ int wl_sim_set_option(wl_sim* s, const char* name, int value) {
   if (n == "resjac") { s->use_resjac = value != 0; s->resjac_force_redo = value == 2 || value == 3; s->redo_unannounced = value == 3; return 0; }   // 2: always take the redo path (tests); 3: the same, unknown to the BC! deferral (tests: its flush before the two-kernel head)
   if (n == "resjac_min") { wl::resjac_enable(1, value); return 0; }                            // cells threshold of the fused head (tests: 0)
   if (n == "convt_min") { wl::conv_tile_min(value); return 0; }                               // tile-planes threshold of the tiled conv_diff! (tests: 0)
+  if (n == "lazydt") { s->use_lazydt = value != 0; return 0; }                                 // wl_sim_mom_steps: between its steps Δt stays on the device until the next predictor is queued (default 1)
   if (n == "tailspec") { s->use_tailspec = value != 0; return 0; }                             // the projection tail is queued ahead of the solver's convergence read, gated by the device's break test (default 1)
   if (n == "headspec") { s->use_headspec = value != 0; return 0; }                             // the first V-cycle is queued behind the fused head before Σr is known (default 1)
   if (n == "bcdefer") { s->use_bcdefer = value != 0; return 0; }                               // mom_step!: BC! after the fused conv_diff!+BDIM! left to the projection (its head reads U on the wall-normal faces, its tail rewrites the boundary); default 1
@@ -906,6 +932,11 @@ int wl_accelerate(float* r, const wl_grid* g, const float* a, void* st) {
   return wl::accelerate(r, gx(*g), a, wl_stream(st));
 }
 int wl_sim_mom_step(wl_sim* s, void* st) { return s->mom_step(wl_stream(st)); }
+int wl_sim_mom_steps(wl_sim* s, int n, void* st) {
+  WL_CHECK(s && n >= 0, "bad argument");
+  for (int k = 0; k < n; k++) WL_TRY(s->mom_step(wl_stream(st), k + 1 < n));
+  return 0;
+}
 int wl_sim_dt(const wl_sim* s, float* out, int cap) { const int n = (int)s->dt.size(); for (int k = 0; k < n && k < cap; k++) out[k] = s->dt[(size_t)k]; return n; }
 float wl_sim_dt_last(const wl_sim* s) { return s->dt.back(); }
 int wl_sim_set_dt_last(wl_sim* s, float dt) { WL_CHECK(s && dt > 0.f, "bad Δt"); s->dt.back() = dt; return 0; }

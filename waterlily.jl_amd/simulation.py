@@ -210,6 +210,14 @@ class FusedSimulation:
         self._forcing()
         check(lib().wl_sim_mom_step(self._h, stream()))
 
+    def mom_steps_(self, n):
+        """n × mom_step! in one library call (no time-dependent uBC / g between the steps: those are evaluated by the host per step — use mom_step_)"""
+        if self._ufn is not None or self._gfn is not None:
+            for _ in range(int(n)):
+                self.mom_step_()
+            return
+        check(lib().wl_sim_mom_steps(self._h, int(n), stream()))
+
     def phase_(self, k):
         check(lib().wl_sim_phase(self._h, int(k), stream()))
 
