@@ -49,8 +49,9 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  const bool contig = getenv("PLACE_CONTIG") != nullptr;      // PLACE_CONTIG=1: hipExtMallocWithFlags(hipDeviceMallocContiguous) — physically contiguous memory
   for (int rd = 0; rd < rounds; rd++) {
-    char* base; CK(hipMalloc(&base, 3 * sp));
+    char* base; if (contig) CK(hipExtMallocWithFlags((void**)&base, 3 * sp, hipDeviceMallocContiguous)); else CK(hipMalloc(&base, 3 * sp));
     float* r = (float*)base; float* ro = (float*)(base + sp); float* eo = (float*)(base + 2 * sp);
     CK(hipMemset(base, 1, 3 * sp));
     float ms[2];

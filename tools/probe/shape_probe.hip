@@ -319,6 +319,9 @@ int main(int argc, char** argv) {
     char* base; CK(hipMalloc(&base, 5 * sp + (4u << 20)));
     e = (float*)base; r = (float*)(base + sp); x = (float*)(base + 2 * sp); ro = (float*)(base + 3 * sp); eo = (float*)(base + 4 * sp);
     printf("# one allocation, spacing %zu + %ld bytes\n", sp - (size_t)delta, delta);
+  } else if (getenv("PLACE_CONTIG")) {   // physically contiguous allocations (hipDeviceMallocContiguous): a deterministic placement
+    for (float** q : {&e, &r, &x, &ro, &eo}) CK(hipExtMallocWithFlags((void**)q, bytes, hipDeviceMallocContiguous));
+    printf("# hipDeviceMallocContiguous\n");
   } else { CK(hipMalloc(&e, bytes)); CK(hipMalloc(&r, bytes)); CK(hipMalloc(&x, bytes)); CK(hipMalloc(&ro, bytes)); CK(hipMalloc(&eo, bytes)); }
   CK(hipMalloc(&sink, 64));
   // random-ish data (DVFS: zero-filled inputs clock higher than real data)
@@ -346,7 +349,7 @@ int main(int argc, char** argv) {
     if (*p == 'G') {   // geometry study on ONE set of allocations (same placement state throughout; run with argv[2] = 576 so that the arrays hold every case):
                        // row pitch and the column of the first interior cell — (514,1) is the reference's layout, (514,2) what modes S/T use, the others padded rows
       const int maxng = NG;
-      static const int geo[][2] = {{514, 1}, {514, 2}, {528, 16}, {576, 64}, {520, 8}, {544, 32}, {512, 0}, {514, 1}};
+      static const int geo[][2] = {{514, 1}, {514, 2}, {528, 16}, {576, 64}, {520, 8}, {544, 32}, {512, 0}, {516, 1}, {518, 1}, {522, 1}, {530, 1}, {514, 1}};
       for (int rep = 0; rep < 2; rep++) for (auto& gq : geo) {
         if (gq[0] > maxng) continue;
         NG = gq[0]; OI = gq[1]; PSZ = (size_t)NG * 514;
